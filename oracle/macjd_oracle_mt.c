@@ -1,0 +1,65 @@
+/*
+ * macjd_oracle_mt.c — OpenMP driver over the scalar oracle.  TEST INFRASTRUCTURE ONLY
+ * (bench.py's cpu_baseline leg times it on the GPU box's host cores; see macjd_oracle.c).
+ * Environments are independent (no cross-env term anywhere in reference
+ * simulation/environment.py:221-477), so the env range is simply cut into contiguous chunks.
+ */
+#include <stddef.h>
+#include <stdint.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/macjd.h"
+
+int macjd_oracle_env_step(const macjd_scenario_desc* d, const macjd_step_io* io, int32_t* draws_out);
+
+static macjd_step_io slice(const macjd_scenario_desc* d, const macjd_step_io* io, int64_t lo, int64_t n) {
+    macjd_step_io s = *io;
+    const int R = d->n_radars, J = d->n_jammers;
+    s.n_envs = n;
+    s.env_offset = io->env_offset + lo;
+    s.T += lo * io->T_se;
+    if (s.P32) s.P32 += lo * io->P_se;
+    if (s.P64) s.P64 += lo * io->P_se;
+    if (s.u) s.u += lo * io->u_se;
+    s.track += lo * io->k_se;
+    s.step += lo;
+    if (s.reward) s.reward += lo;
+    if (s.r_dpj) s.r_dpj += lo * 3;
+    if (s.terminated) s.terminated += lo;
+    if (s.pd) s.pd += lo * io->pd_se;
+    if (s.snr_with) s.snr_with += lo * io->sw_se;
+    if (s.out64) s.out64 += lo * 4;
+    if (s.pd64) s.pd64 += lo * R;
+    if (s.snr64) s.snr64 += lo * R;
+    if (s.prj64) s.prj64 += lo * J;
+    return s;
+}
+
+int macjd_oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+int macjd_oracle_env_step_mt(const macjd_scenario_desc* d, const macjd_step_io* io, int n_threads) {
+    if (n_threads < 1) n_threads = 1;
+    const int64_t E = io->n_envs;
+    int rc = 0;
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+    for (int t = 0; t < n_threads; ++t) {
+        int64_t lo = E * t / n_threads, hi = E * (t + 1) / n_threads;
+        if (hi > lo) {
+            macjd_step_io s = slice(d, io, lo, hi - lo);
+            int r = macjd_oracle_env_step(d, &s, NULL);
+            if (r != 0) {
+#pragma omp critical
+                rc = r;
+            }
+        }
+    }
+    return rc;
+}
