@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec/GPU on the BASELINE.json workload (3 jammers / 4 radars, batch_envs=4096).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode env|rollout|train] [--sweep]
+
+One "step" = one pass of the hot path over one batch of E environments per GPU.  Modes:
+  env      the HIP env-step kernel alone (Philox uniforms in-kernel, synthetic actions resident in HBM)
+  rollout  agent forward + MP-DQN multi-pass Q + eps-greedy + env-step kernel + replay write
+  train    rollout + QMixLearner.train at the reference cadence (default when available)
+For N>1 launch through torch.distributed.run (one rank per GPU, RCCL); envs shard across ranks with
+no data-path collective in env/rollout mode ("weak" scaling); train mode all-reduces the gradients.
+
+Prints ONE JSON line (rank 0) with the contract keys plus `roofline` (env-step kernel, HBM bound,
+timed with HIP events on the launch stream) and `cpu_baseline` (the C oracle timed on host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_env_step(J, R, uniforms_supplied, info_outputs=True):
+    """DESIGN.md section 'Algorithmic bytes': what one env-step must move through HBM.
+    reads : T 4J + P 4J + step 4 (+ uniforms, counted as SURVEY.md 8(d) does, 4(R+J), when supplied)
+    writes: reward 4 + (r_d,r_p,r_j) 12 + terminated 1 + track R + step 4 (+ pd 4R + snr_with 4R info)
+    The FSM's next state does not depend on the previous one (core/radar.py:102-117), so `track` is
+    written, never read."""
+    b = 4 * J + 4 * J + 4 + 4 + 12 + 1 + R + 4
+    if uniforms_supplied:
+        b += 4 * (R + J)
+    if info_outputs:
+        b += 8 * R
+    return b
+
+
+def dist_setup(n_gpus):
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    return rank, world, local
+
+
+def cpu_baseline(sc, E, seed, budget_s=12.0):
+    """Times the CPU oracle (oracle/libmacjd_oracle.so, a port of the reference's step; kind="port")
+    on a bounded sample of the same workload: E envs x as many steps as fit in ~budget_s seconds."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from _harness import OracleEnv, oracle_lib
+    rng = np.random.default_rng(seed)
+    J, R = sc.num_jammers, sc.num_radars
+    T = rng.integers(0, 2 * R + 1, size=(E, J)).astype(np.int32)
+    P = rng.random((E, J)).astype(np.float32)
+    out = {}
+    cores_all = min(oracle_lib().macjd_oracle_max_threads(), os.cpu_count() or 1)
+    for label, nt in (("1", 1), ("all", cores_all)):
+        env = OracleEnv(sc, E, n_threads=nt)
+        env.step(T, P, seed=seed)  # warm
+        n, t0 = 0, time.perf_counter()
+        while True:
+            env.step(T, P, seed=seed)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s / 2 or n >= 2000:
+                break
+        out[label] = (E * n / dt, nt, n)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--mode", default="auto", choices=["auto", "env", "rollout", "train"])
+    ap.add_argument("--batch-envs", type=int, default=4096)
+    ap.add_argument("--jammers", type=int, default=3)
+    ap.add_argument("--radars", type=int, default=4)
+    ap.add_argument("--hidden", type=int, default=64)
+    ap.add_argument("--sweep", action="store_true", help="also print an E-sweep of the env kernel (stderr)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as entry
+    rank, world, local = dist_setup(args.gpus)
+    if rank == 0:
+        entry.build()
+    if world > 1:
+        torch.distributed.barrier()
+    from macjd_amd.scenario import Scenario, ring_scenario_dict
+    from macjd_amd.simulation.environment import BatchedElectromagneticEnvironment
+
+    J, R, E = args.jammers, args.radars, args.batch_envs
+    sc = Scenario.from_dict(ring_scenario_dict(J, R))
+    dev = torch.device("cuda", local)
+    mode = args.mode
+    bench_mod = None
+    if mode in ("auto", "rollout", "train"):
+        try:
+            from macjd_amd import bench_rollout as bench_mod  # provided once the agent path exists
+        except ImportError:
+            if mode != "auto":
+                raise
+        mode = ("train" if bench_mod is not None else "env") if mode == "auto" else mode
+
+    env = BatchedElectromagneticEnvironment(scenario=sc, batch_envs=E, device=dev, seed=42, env_offset=rank * E)
+    env.reset()
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    # synthetic actions, agent-major storage [J, E] (T ~ U{0..2R}, P ~ U[0,1))
+    T_am = torch.randint(0, 2 * R + 1, (J, E), generator=g, device=dev, dtype=torch.int32)
+    P_am = torch.rand((J, E), generator=g, device=dev)
+    T, P = T_am.t(), P_am.t()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    if mode == "env":
+        def step_fn(i):
+            if i % sc.episode_limit == 0:
+                env.reset()
+            env.step(T, P)
+        extra = {}
+    else:
+        step_fn, extra = bench_mod.make_step(args, sc, env, dev, rank, world, mode)
+
+    for i in range(args.warmup):
+        step_fn(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step_fn(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- roofline of the env-step kernel: HIP events on the launch stream ----
+    ms = env.time_step_kernel(T, P, iters=200)
+    B_step = algorithmic_bytes_per_env_step(J, R, uniforms_supplied=False)
+    achieved = E * B_step / (ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "kernel": f"env_step_kernel<{J},{R}>", "us_per_launch": round(ms * 1e3, 3),
+                "bytes_per_env_step": B_step, "envs_per_launch": E}
+    sweep = None
+    if args.sweep and rank == 0:
+        sweep = []
+        for logE in (12, 14, 16, 18, 20, 22):
+            Es = 1 << logE
+            e2 = BatchedElectromagneticEnvironment(scenario=sc, batch_envs=Es, device=dev, seed=1)
+            Ts = torch.randint(0, 2 * R + 1, (J, Es), generator=g, device=dev, dtype=torch.int32).t()
+            Ps = torch.rand((J, Es), generator=g, device=dev).t()
+            e2.time_step_kernel(Ts, Ps, iters=5)
+            m = e2.time_step_kernel(Ts, Ps, iters=50)
+            gbs = Es * B_step / (m * 1e-3) / 1e9
+            sweep.append({"E": Es, "us": round(m * 1e3, 2), "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)})
+            print(f"[sweep] E=2^{logE} {m*1e3:9.2f} us/launch  {gbs:8.1f} GB/s  frac {gbs/HBM_PEAK_GBS:.4f}",
+                  file=sys.stderr, flush=True)
+            e2.close()
+
+    if rank == 0:
+        res = {
+            "metric": "env-steps/sec (all GPUs; batch_envs=%d/GPU, %dj/%dr)" % (E, J, R),
+            "value": round(E * world * args.steps / dt, 1), "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{J} jammers / {R} radars, batch_envs={E} per GPU, GRU hidden={args.hidden}",
+                       "mode": mode, "per_gpu_env_steps_per_s": round(E * args.steps / dt, 1), **extra},
+            "roofline": roofline,
+        }
+        if sweep:
+            res["env_kernel_sweep"] = sweep
+        if not args.no_cpu_baseline:
+            cb = cpu_baseline(sc, E, seed=42)
+            res["cpu_baseline"] = {"value": round(cb["all"][0], 1), "unit": "env-steps/s", "cores": cb["all"][1],
+                                   "kind": "port",
+                                   "sample": f"C oracle of env.step, {E} envs x {cb['all'][2]} steps, OpenMP",
+                                   "single_core_value": round(cb["1"][0], 1)}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

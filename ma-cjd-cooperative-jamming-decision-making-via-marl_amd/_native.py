@@ -1,0 +1,118 @@
+"""ctypes binding of libmacjd_hip.so (C-ABI in include/macjd.h).
+
+There is deliberately NO fallback: if the HIP library is missing or no HIP device is present, every
+entry point raises.  The CPU restatement under oracle/ is test infrastructure and is never imported
+from here."""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libmacjd_hip.so"
+LIB_PATH = os.path.join(_PKG_DIR, LIB_NAME)
+
+ABI_VERSION = 1
+STEP_ARITH_F64 = 1
+
+EXPORTS = [
+    "macjd_abi_version", "macjd_last_error", "macjd_device_count",
+    "macjd_scenario_create", "macjd_scenario_destroy", "macjd_scenario_dims",
+    "macjd_env_reset", "macjd_env_step", "macjd_env_step_timed",
+]
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+class StepIO(ctypes.Structure):
+    """ctypes mirror of ``macjd_step_io`` (include/macjd.h)."""
+    _fields_ = [
+        ("n_envs", ctypes.c_int64), ("env_offset", ctypes.c_int64), ("seed", ctypes.c_uint64),
+        ("flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+        ("T", ctypes.c_void_p), ("T_se", ctypes.c_int64), ("T_sx", ctypes.c_int64),
+        ("P32", ctypes.c_void_p), ("P64", ctypes.c_void_p), ("P_se", ctypes.c_int64), ("P_sx", ctypes.c_int64),
+        ("u", ctypes.c_void_p), ("u_se", ctypes.c_int64), ("u_sx", ctypes.c_int64),
+        ("track", ctypes.c_void_p), ("k_se", ctypes.c_int64), ("k_sx", ctypes.c_int64),
+        ("step", ctypes.c_void_p),
+        ("reward", ctypes.c_void_p), ("r_dpj", ctypes.c_void_p), ("terminated", ctypes.c_void_p),
+        ("pd", ctypes.c_void_p), ("pd_se", ctypes.c_int64), ("pd_sx", ctypes.c_int64),
+        ("snr_with", ctypes.c_void_p), ("sw_se", ctypes.c_int64), ("sw_sx", ctypes.c_int64),
+        ("out64", ctypes.c_void_p), ("pd64", ctypes.c_void_p), ("snr64", ctypes.c_void_p),
+        ("prj64", ctypes.c_void_p),
+    ]
+
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libmacjd_hip.so from the package directory; raise loudly when it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(hipcc --offload-arch=gfx950). There is no CPU fallback for the environment step.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # missing ROCm runtime etc.
+        raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    lib.macjd_abi_version.restype = ctypes.c_int
+    lib.macjd_last_error.restype = ctypes.c_char_p
+    lib.macjd_device_count.restype = ctypes.c_int
+    lib.macjd_scenario_create.restype = ctypes.c_int
+    lib.macjd_scenario_create.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+    lib.macjd_scenario_destroy.restype = None
+    lib.macjd_scenario_destroy.argtypes = [ctypes.c_void_p]
+    lib.macjd_scenario_dims.restype = ctypes.c_int
+    lib.macjd_scenario_dims.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int32)] * 3
+    lib.macjd_env_reset.restype = ctypes.c_int
+    lib.macjd_env_reset.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.macjd_env_step.restype = ctypes.c_int
+    lib.macjd_env_step.argtypes = [ctypes.c_void_p, ctypes.POINTER(StepIO), ctypes.c_void_p]
+    lib.macjd_env_step_timed.restype = ctypes.c_int
+    lib.macjd_env_step_timed.argtypes = [ctypes.c_void_p, ctypes.POINTER(StepIO), ctypes.c_int, ctypes.c_void_p,
+                                         ctypes.POINTER(ctypes.c_float)]
+    if lib.macjd_abi_version() != ABI_VERSION:
+        raise NativeLibraryError(f"{LIB_NAME}: ABI version {lib.macjd_abi_version()} != expected {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().macjd_last_error()
+        raise NativeLibraryError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+class ScenarioHandle:
+    """Owns a ``macjd_scenario*`` (device copy of the scenario tables)."""
+
+    def __init__(self, scenario):
+        lib = load()
+        desc, keep = scenario.c_desc()
+        h = ctypes.c_void_p()
+        check(lib.macjd_scenario_create(ctypes.addressof(desc), ctypes.byref(h)), "macjd_scenario_create")
+        del keep
+        self._h = h
+        self._lib = lib
+
+    @property
+    def ptr(self):
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.macjd_scenario_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,393 @@
+// macjd_env.hip — batched radar-jamming environment step for MI355X (gfx950, wave64).
+//
+// One lane = one environment.  The kernel is the batched form of
+// ElectromagneticEnvironment.step (reference simulation/environment.py:221-477) with the helpers it
+// calls (core/radar.py:67-82 detection probability, :90-119 SEARCH/TRACK FSM; core/jammer.py:56-98
+// received jamming power).  All arithmetic is float64 in the reference's operation order (the TU is
+// built with -ffp-contract=off: Python never fuses multiply-add), except the power /
+// received-power numerator which follows NumPy-2's float32 weak-scalar promotion when the power
+// action arrives as float32 (see include/macjd.h, MACJD_STEP_ARITH_F64).
+//
+// Data movement (HBM-bound streaming kernel; see DESIGN.md for the byte count):
+//   * per-env inputs/outputs are addressed through caller-supplied element strides, so the runner
+//     can keep actions agent-major ([J,E]: every load instruction is a fully coalesced 256-B row) while
+//     the reference-shaped env-major layout ([E,J]) stays valid;
+//   * per-radar constants that are indexed by the (compile-time unrolled) radar loop are read
+//     through wave-uniform scalar loads from the scenario table;
+//   * tables that are indexed by the lane's *chosen target radar* (jammer->radar path denominators,
+//     D, Pn, receive gain) are staged once per workgroup into LDS and gathered with ds_read.
+//
+// The whole scenario is templated on (J, R) for the BASELINE.json configurations so that the
+// suppression / deception accumulators live in registers; a generic (0,0) instantiation covers
+// every other size up to MACJD_MAX_*.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/macjd.h"
+#include "macjd_philox.h"
+
+namespace macjd {
+
+constexpr int MAXR = MACJD_MAX_RADARS;
+constexpr int MAXJ = MACJD_MAX_JAMMERS;
+
+// Device-resident scenario tables (one per scenario handle).
+struct DevTables {
+    int32_t R, J, episode_limit, pad;
+    double rp_min, rp_max, pd_A, pd_c1, pd_denB;
+    double GaPs[MAXR], Pn[MAXR], D[MAXR], pd_no[MAXR], rd_pen[MAXR], gr[MAXR];
+    double pmin[MAXJ], pmax[MAXJ], gj[MAXJ];
+    double denom[MAXJ * MAXR];   // packed [j*R + r]; negative = jammer sits on the radar (ignored)
+    uint8_t flags[MAXJ * MAXR];  // packed [j*R + r]
+};
+
+static thread_local char g_err[512] = "";
+static int set_err(int code, const char* fmt, const char* a = "") {
+    snprintf(g_err, sizeof(g_err), fmt, a);
+    return code;
+}
+
+// core/radar.py:67-82, constants precomputed on the host (A, c1, denB)
+__device__ __forceinline__ double det_prob(double snr, double A, double c1, double denB) {
+    const double s = (0.0 > snr) ? 0.0 : snr;  // Python max(snr, 0.0)
+    const double Z = s + c1;
+    const double B = (10.0 * Z - A) / denB;
+    double p = 1.0 / (1.0 + exp(-B));
+    p = (B > 700.0) ? 1.0 : p;
+    p = (B < -700.0) ? 0.0 : p;
+    return (fabs(denB) < 1e-9) ? 0.0 : p;
+}
+
+__device__ __forceinline__ double draw_uniform(const macjd_step_io& io, int64_t e, int slot, uint32_t step_before) {
+    if (io.u) return io.u[e * io.u_se + (int64_t)slot * io.u_sx];
+    const uint64_t genv = (uint64_t)(io.env_offset + e);
+    const Philox4 r = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), step_before, (uint32_t)(slot >> 1),
+                                    (uint32_t)io.seed, (uint32_t)(io.seed >> 32));
+    return (slot & 1) ? u53(r.v[2], r.v[3]) : u53(r.v[0], r.v[1]);
+}
+
+template <int JT, int RT>
+__global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restrict__ tb, const macjd_step_io io) {
+    constexpr int NJ = JT ? JT : MAXJ;
+    constexpr int NR = RT ? RT : MAXR;
+    const int J = JT ? JT : tb->J;
+    const int R = RT ? RT : tb->R;
+
+    // ---- LDS staging of the tables gathered by per-lane target index ----
+    __shared__ double s_denom[NJ * NR];
+    __shared__ double s_D[NR], s_Pn[NR], s_gr[NR];
+    __shared__ uint8_t s_flags[NJ * NR];
+    for (int i = threadIdx.x; i < J * R; i += blockDim.x) {
+        s_denom[i] = tb->denom[i];
+        s_flags[i] = tb->flags[i];
+    }
+    for (int i = threadIdx.x; i < R; i += blockDim.x) {
+        s_D[i] = tb->D[i];
+        s_Pn[i] = tb->Pn[i];
+        s_gr[i] = tb->gr[i];
+    }
+    __syncthreads();
+
+    const double rp_min = tb->rp_min, rp_max = tb->rp_max;
+    const double pdA = tb->pd_A, pdc1 = tb->pd_c1, pdden = tb->pd_denB;
+    const int32_t episode_limit = tb->episode_limit;
+    const bool arith32 = (io.P32 != nullptr) && !(io.flags & MACJD_STEP_ARITH_F64);
+
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < io.n_envs;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t step_before = io.step[e];
+        const int32_t step_count = step_before + 1;  // environment.py:235
+
+        double supp[NR];   // environment.py:241
+        double prod[NR];   // environment.py:443-447
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { supp[r] = 0.0; prod[r] = 1.0; }
+        uint32_t supp_mask = 0;  // environment.py:391-394 (set of suppressed radars)
+        uint32_t hit_mask = 0;   // radars with >= 1 detected false target
+        int n_dec = 0;           // valid deception actions so far (RNG slot R + k)
+        double r_p = 0.0;        // environment.py:371-378
+
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (!JT && j >= J) break;
+            // ---- action decode, environment.py:249-268 ----
+            const int32_t T = io.T[e * io.T_se + (int64_t)j * io.T_sx];
+            const bool is_jamming = (T >= 1) && (T <= 2 * R);
+            const int target = is_jamming ? ((T + 1) / 2 - 1) : 0;
+            const int jtype = T % 2;  // 1 = suppression, 0 = deception (only read when is_jamming)
+
+            // ---- power scale + r_p term, environment.py:271-277 ----
+            const double pmin = tb->pmin[j], pmax = tb->pmax[j];
+            const double power_range = pmax - pmin;
+            double actual_d, norm;
+            float actual_f = 0.0f;
+            if (arith32) {
+                float Pc = io.P32[e * io.P_se + (int64_t)j * io.P_sx];
+                Pc = Pc < 0.0f ? 0.0f : (Pc > 1.0f ? 1.0f : Pc);  // np.clip, NaN propagates
+                actual_f = (float)pmin + Pc * (float)power_range;
+                actual_d = (double)actual_f;
+                norm = (power_range > 1e-6) ? (double)((actual_f - (float)pmin) / (float)power_range) : 0.0;
+            } else {
+                double Pc = io.P64 ? io.P64[e * io.P_se + (int64_t)j * io.P_sx]
+                                   : (double)io.P32[e * io.P_se + (int64_t)j * io.P_sx];
+                Pc = Pc < 0.0 ? 0.0 : (Pc > 1.0 ? 1.0 : Pc);
+                actual_d = pmin + Pc * power_range;
+                norm = (power_range > 1e-6) ? (actual_d - pmin) / power_range : 0.0;
+            }
+            r_p += rp_max + (rp_min - rp_max) * norm;  // environment.py:377-378
+
+            // ---- received jamming power, environment.py:280-302, jammer.py:56-98 ----
+            const double denom = s_denom[j * R + target];
+            const bool recorded = is_jamming && (actual_d > 0.0) && (denom >= 0.0);
+            double prj = 0.0;
+            if (recorded && denom > 1e-18) {
+                const double grj = s_gr[target];
+                if (arith32) {
+                    const float num = (actual_f * (float)tb->gj[j]) * (float)grj;
+                    prj = (s_flags[j * R + target] & MACJD_JR_WEAK_DENOM) ? (double)(num / (float)denom)
+                                                                         : (double)num / denom;
+                } else {
+                    prj = (actual_d * tb->gj[j] * grj) / denom;
+                }
+                prj = (prj > 0.0) ? prj : 0.0;  // Python max(0.0, x)
+            }
+            if (io.prj64) io.prj64[e * J + j] = recorded ? prj : -1.0;
+
+            const bool is_sup = recorded && (jtype == 1);
+            const bool is_dec = recorded && (jtype == 0);
+            supp_mask |= is_sup ? (1u << target) : 0u;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) supp[r] += (is_sup && target == r) ? prj : 0.0;  // environment.py:299
+
+            // ---- deception: false-target detection, environment.py:410-434 ----
+            if (is_dec) {
+                const double Pn_t = s_Pn[target];
+                double snr_f = (Pn_t > 1e-18) ? (s_D[target] * prj) / Pn_t : 0.0;
+                snr_f = (snr_f > 0.0) ? snr_f : 0.0;
+                const double pd_f = det_prob(snr_f, pdA, pdc1, pdden);
+                const double u = draw_uniform(io, e, R + n_dec, (uint32_t)step_before);
+                ++n_dec;
+                if (u <= pd_f) {
+                    const double safe = pd_f < 0.999999 ? pd_f : 0.999999;  // environment.py:446
+                    hit_mask |= (1u << target);
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) prod[r] = (target == r) ? prod[r] * (1.0 - safe) : prod[r];
+                }
+            }
+        }
+
+        // ---- detections, FSM, r_d, r_j(suppression); environment.py:316-398 ----
+        double r_d = 0.0, r_j = 0.0, r_j_dec = 0.0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (!RT && r >= R) break;
+            const double Pn = tb->Pn[r];
+            const double den = tb->D[r] * supp[r] + Pn;                       // :331
+            const double snr_with = (den > 1e-18) ? tb->GaPs[r] / den : 0.0;  // :332
+            const double pd = det_prob(snr_with, pdA, pdc1, pdden);           // :337
+            const double u = draw_uniform(io, e, r, (uint32_t)step_before);
+            const bool detected = (u <= pd);                                   // :341
+            // radar.py:102-117: SEARCH & detected -> TRACK, SEARCH & !detected -> SEARCH,
+            // TRACK & !detected -> SEARCH, TRACK & detected -> TRACK.  The next state therefore
+            // equals `detected` whatever the previous state was, so the previous state is never
+            // read (saves R bytes of HBM reads per env-step); `track` is write-only here.
+            const bool tracking = detected;
+            io.track[e * io.k_se + (int64_t)r * io.k_sx] = tracking ? 1 : 0;
+            r_d += tracking ? tb->rd_pen[r] : 0.0;                             // :359-366 (post-update state)
+            if (supp_mask & (1u << r)) {                                       // :396-398
+                const double red = tb->pd_no[r] - pd;
+                r_j += (red > 0.0) ? red : 0.0;
+            }
+            if (hit_mask & (1u << r)) r_j_dec += 1.0 - prod[r];               // :438-451
+            const double snr_rep = (snr_with > 0.0) ? snr_with : 0.0;         // :333
+            if (io.pd) io.pd[e * io.pd_se + (int64_t)r * io.pd_sx] = (float)pd;
+            if (io.snr_with) io.snr_with[e * io.sw_se + (int64_t)r * io.sw_sx] = (float)snr_rep;
+            if (io.pd64) io.pd64[e * R + r] = pd;
+            if (io.snr64) io.snr64[e * R + r] = snr_rep;
+        }
+        r_j += r_j_dec;                          // :454
+        const double reward = r_d + r_p + r_j;  // :457
+
+        io.step[e] = step_count;
+        if (io.terminated) io.terminated[e] = (step_count >= episode_limit) ? 1 : 0;  // :460
+        if (io.reward) io.reward[e] = (float)reward;
+        if (io.r_dpj) {
+            io.r_dpj[e * 3 + 0] = (float)r_d;
+            io.r_dpj[e * 3 + 1] = (float)r_p;
+            io.r_dpj[e * 3 + 2] = (float)r_j;
+        }
+        if (io.out64) {
+            io.out64[e * 4 + 0] = reward;
+            io.out64[e * 4 + 1] = r_d;
+            io.out64[e * 4 + 2] = r_p;
+            io.out64[e * 4 + 3] = r_j;
+        }
+    }
+}
+
+__global__ void env_reset_kernel(int64_t n_envs, int R, uint8_t* track, int64_t k_se, int64_t k_sx, int32_t* step,
+                                 const uint8_t* mask) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_envs;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        if (mask && !mask[e]) continue;
+        for (int r = 0; r < R; ++r) track[e * k_se + (int64_t)r * k_sx] = 0;  // radar.py:10 initial_state SEARCH
+        step[e] = 0;                                                         // environment.py:203
+    }
+}
+
+}  // namespace macjd
+
+using macjd::DevTables;
+using macjd::set_err;
+
+struct macjd_scenario {
+    DevTables host;
+    DevTables* dev;
+    int device;
+};
+
+extern "C" {
+
+int macjd_abi_version(void) { return MACJD_ABI_VERSION; }
+const char* macjd_last_error(void) { return macjd::g_err; }
+
+int macjd_device_count(void) {
+    int n = 0;
+    hipError_t err = hipGetDeviceCount(&n);
+    if (err != hipSuccess) return set_err(MACJD_EDEVICE, "hipGetDeviceCount: %s", hipGetErrorString(err));
+    return n;
+}
+
+int macjd_scenario_create(const macjd_scenario_desc* d, macjd_scenario** out) {
+    if (!d || !out) return set_err(MACJD_EINVAL, "macjd_scenario_create: NULL argument");
+    const int R = d->n_radars, J = d->n_jammers;
+    if (R < 1 || R > MACJD_MAX_RADARS || J < 1 || J > MACJD_MAX_JAMMERS)
+        return set_err(MACJD_EINVAL, "macjd_scenario_create: n_radars / n_jammers out of range");
+    if (!d->radar_GaPs || !d->radar_Pn || !d->radar_D || !d->radar_pd_no || !d->radar_rd_pen || !d->radar_gr ||
+        !d->jam_pmin || !d->jam_pmax || !d->jam_gj || !d->jr_denom || !d->jr_flags)
+        return set_err(MACJD_EINVAL, "macjd_scenario_create: NULL table pointer");
+    macjd_scenario* s = new (std::nothrow) macjd_scenario();
+    if (!s) return set_err(MACJD_ENOMEM, "macjd_scenario_create: host allocation failed");
+    DevTables& t = s->host;
+    memset(&t, 0, sizeof(t));
+    t.R = R; t.J = J; t.episode_limit = d->episode_limit;
+    t.rp_min = d->rp_min; t.rp_max = d->rp_max;
+    t.pd_A = d->pd_A; t.pd_c1 = d->pd_c1; t.pd_denB = d->pd_denB;
+    for (int r = 0; r < R; ++r) {
+        t.GaPs[r] = d->radar_GaPs[r]; t.Pn[r] = d->radar_Pn[r]; t.D[r] = d->radar_D[r];
+        t.pd_no[r] = d->radar_pd_no[r]; t.rd_pen[r] = d->radar_rd_pen[r]; t.gr[r] = d->radar_gr[r];
+    }
+    for (int j = 0; j < J; ++j) {
+        t.pmin[j] = d->jam_pmin[j]; t.pmax[j] = d->jam_pmax[j]; t.gj[j] = d->jam_gj[j];
+    }
+    for (int i = 0; i < J * R; ++i) { t.denom[i] = d->jr_denom[i]; t.flags[i] = d->jr_flags[i]; }
+    hipError_t err = hipGetDevice(&s->device);
+    if (err == hipSuccess) err = hipMalloc((void**)&s->dev, sizeof(DevTables));
+    if (err == hipSuccess) err = hipMemcpy(s->dev, &t, sizeof(DevTables), hipMemcpyHostToDevice);
+    if (err != hipSuccess) {
+        if (s->dev) (void)hipFree(s->dev);
+        delete s;
+        return set_err(MACJD_EDEVICE, "macjd_scenario_create: %s", hipGetErrorString(err));
+    }
+    *out = s;
+    return MACJD_OK;
+}
+
+void macjd_scenario_destroy(macjd_scenario* s) {
+    if (!s) return;
+    if (s->dev) (void)hipFree(s->dev);
+    delete s;
+}
+
+int macjd_scenario_dims(const macjd_scenario* s, int32_t* n_radars, int32_t* n_jammers, int32_t* episode_limit) {
+    if (!s) return set_err(MACJD_EINVAL, "macjd_scenario_dims: NULL scenario");
+    if (n_radars) *n_radars = s->host.R;
+    if (n_jammers) *n_jammers = s->host.J;
+    if (episode_limit) *episode_limit = s->host.episode_limit;
+    return MACJD_OK;
+}
+
+int macjd_env_reset(const macjd_scenario* s, int64_t n_envs, uint8_t* track, int64_t k_se, int64_t k_sx,
+                    int32_t* step, const uint8_t* mask, void* hip_stream) {
+    if (!s || !track || !step || n_envs < 0) return set_err(MACJD_EINVAL, "macjd_env_reset: bad argument");
+    if (n_envs == 0) return MACJD_OK;
+    const int block = 256;
+    int64_t grid = (n_envs + block - 1) / block;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(macjd::env_reset_kernel, dim3((unsigned)grid), dim3(block), 0, (hipStream_t)hip_stream, n_envs,
+                       s->host.R, track, k_se, k_sx, step, mask);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_env_reset launch: %s", hipGetErrorString(err));
+    return MACJD_OK;
+}
+
+static int validate_io(const macjd_scenario* s, const macjd_step_io* io) {
+    if (!s || !io) return set_err(MACJD_EINVAL, "macjd_env_step: NULL scenario / io");
+    if (io->n_envs < 0) return set_err(MACJD_EINVAL, "macjd_env_step: n_envs < 0");
+    if (!io->T || !io->track || !io->step) return set_err(MACJD_EINVAL, "macjd_env_step: T / track / step is NULL");
+    if ((io->P32 == nullptr) == (io->P64 == nullptr))
+        return set_err(MACJD_EINVAL, "macjd_env_step: exactly one of P32 / P64 must be given");
+    if ((io->pd && (io->pd_se == 0 && io->pd_sx == 0)) || (io->snr_with && (io->sw_se == 0 && io->sw_sx == 0)))
+        return set_err(MACJD_EINVAL, "macjd_env_step: output strides are zero");
+    if (io->k_se == 0 && io->k_sx == 0) return set_err(MACJD_EINVAL, "macjd_env_step: track strides are zero");
+    return MACJD_OK;
+}
+
+static int launch_step(const macjd_scenario* s, const macjd_step_io* io, hipStream_t stream) {
+    const int64_t E = io->n_envs;
+    // small batches: one wave per workgroup spreads the envs over more CUs (latency-bound regime);
+    // large batches: 256-lane workgroups, grid-stride, tables staged once per workgroup.
+    const int block = (E >= (1 << 16)) ? 256 : 64;
+    int64_t grid = (E + block - 1) / block;
+    const int64_t cap = (block == 256) ? 256 * 8 : 256 * 16;
+    if (grid > cap) grid = cap;
+    const dim3 g((unsigned)grid), b(block);
+    const int J = s->host.J, R = s->host.R;
+#define MACJD_LAUNCH(JT, RT) hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT>), g, b, 0, stream, s->dev, *io)
+    if (J == 3 && R == 4) MACJD_LAUNCH(3, 4);
+    else if (J == 6 && R == 8) MACJD_LAUNCH(6, 8);
+    else if (J == 12 && R == 16) MACJD_LAUNCH(12, 16);
+    else if (J == 2 && R == 2) MACJD_LAUNCH(2, 2);
+    else MACJD_LAUNCH(0, 0);
+#undef MACJD_LAUNCH
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_env_step launch: %s", hipGetErrorString(err));
+    return MACJD_OK;
+}
+
+int macjd_env_step(const macjd_scenario* s, const macjd_step_io* io, void* hip_stream) {
+    int rc = validate_io(s, io);
+    if (rc != MACJD_OK) return rc;
+    if (io->n_envs == 0) return MACJD_OK;
+    return launch_step(s, io, (hipStream_t)hip_stream);
+}
+
+int macjd_env_step_timed(const macjd_scenario* s, const macjd_step_io* io, int iters, void* hip_stream,
+                         float* ms_per_launch) {
+    int rc = validate_io(s, io);
+    if (rc != MACJD_OK) return rc;
+    if (iters < 1 || !ms_per_launch) return set_err(MACJD_EINVAL, "macjd_env_step_timed: bad iters / output");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    hipEvent_t t0, t1;
+    hipError_t err = hipEventCreate(&t0);
+    if (err != hipSuccess) return set_err(MACJD_EDEVICE, "hipEventCreate: %s", hipGetErrorString(err));
+    err = hipEventCreate(&t1);
+    if (err != hipSuccess) { (void)hipEventDestroy(t0); return set_err(MACJD_EDEVICE, "hipEventCreate: %s", hipGetErrorString(err)); }
+    (void)hipEventRecord(t0, stream);
+    for (int i = 0; i < iters && rc == MACJD_OK; ++i) rc = launch_step(s, io, stream);
+    (void)hipEventRecord(t1, stream);
+    err = hipEventSynchronize(t1);
+    float ms = 0.f;
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, t0, t1);
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    if (rc != MACJD_OK) return rc;
+    if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_env_step_timed: %s", hipGetErrorString(err));
+    *ms_per_launch = ms / (float)iters;
+    return MACJD_OK;
+}
+
+}  // extern "C"

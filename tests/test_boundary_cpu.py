@@ -1,0 +1,158 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library exports every symbol include/macjd.h
+declares (no compute calls without a GPU), the scenario front-end validates like the reference
+(simulation/environment.py:44-79,133-199), and the product path refuses to run without a HIP device
+instead of silently falling back to a CPU implementation."""
+import ctypes
+import os
+import re
+import subprocess
+import tempfile
+from types import SimpleNamespace
+
+import pytest
+import yaml
+
+import __graft_entry__ as entry
+from _harness import REPO, StepIO as HarnessStepIO, load_scenario
+
+from macjd_amd import _native
+from macjd_amd.scenario import Scenario, _Desc, ring_scenario_dict
+
+
+@pytest.fixture(scope="module")
+def built():
+    entry.build()
+    return ctypes.CDLL(_native.LIB_PATH)
+
+
+def _write(d):
+    p = os.path.join(tempfile.mkdtemp(prefix="macjd_sc_"), "s.yaml")
+    with open(p, "w") as f:
+        yaml.safe_dump(d, f)
+    return p
+
+
+def test_library_exports_every_declared_symbol(built):
+    hdr = open(os.path.join(REPO, "include", "macjd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(macjd_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_native.EXPORTS), declared ^ set(_native.EXPORTS)
+    for sym in declared:
+        assert hasattr(built, sym), sym
+    built.macjd_abi_version.restype = ctypes.c_int
+    assert built.macjd_abi_version() == _native.ABI_VERSION
+
+
+def test_step_io_struct_layout_matches_header():
+    """ctypes mirrors (product and test harness) agree with each other and with the C struct layout."""
+    assert ctypes.sizeof(_native.StepIO) == ctypes.sizeof(HarnessStepIO)
+    assert [f[0] for f in _native.StepIO._fields_] == [f[0] for f in HarnessStepIO._fields_]
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "macjd.h"\n'
+           'int main(){printf("%zu %zu %zu %zu\\n", sizeof(macjd_step_io), sizeof(macjd_scenario_desc), '
+           'offsetof(macjd_step_io, prj64), offsetof(macjd_step_io, track));return 0;}\n')
+    d = tempfile.mkdtemp()
+    with open(os.path.join(d, "t.c"), "w") as f:
+        f.write(src)
+    subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), "-o", os.path.join(d, "t"),
+                    os.path.join(d, "t.c")], check=True)
+    out = subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split()
+    assert int(out[0]) == ctypes.sizeof(_native.StepIO)
+    assert int(out[1]) == ctypes.sizeof(_Desc)
+    assert int(out[2]) == _native.StepIO.prj64.offset
+    assert int(out[3]) == _native.StepIO.track.offset
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from macjd_amd.simulation.environment import BatchedElectromagneticEnvironment, ElectromagneticEnvironment
+    sc = Scenario.from_dict(ring_scenario_dict(3, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        BatchedElectromagneticEnvironment(scenario=sc, batch_envs=4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ElectromagneticEnvironment(SimpleNamespace(), _write(ring_scenario_dict(2, 2)))
+
+
+def test_product_never_references_oracle():
+    pkg = os.path.join(REPO, "ma-cjd-cooperative-jamming-decision-making-via-marl_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(root, f)).read()
+                assert "libmacjd_oracle" not in txt and "macjd_oracle_" not in txt, f
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+
+
+def test_scenario_validation_matches_reference_errors(capsys):
+    good = ring_scenario_dict(2, 2)
+    with pytest.raises(FileNotFoundError):
+        Scenario.from_yaml("/nonexistent/sim.yaml")
+    bad = os.path.join(os.path.dirname(_write(good)), "bad.yaml")
+    with open(bad, "w") as f:
+        f.write("radars: [1, 2\n")
+    with pytest.raises(yaml.YAMLError):
+        Scenario.from_yaml(bad)
+    with pytest.raises(ValueError, match="missing required 'radars' or 'jammers' keys"):
+        Scenario.from_dict({"radars": []})
+    d = ring_scenario_dict(2, 2); d.pop("protected_target")
+    with pytest.raises(ValueError, match="missing required 'protected_target' key"):
+        Scenario.from_dict(d)
+    d = ring_scenario_dict(2, 2); d["protected_target"].pop("rcs")
+    with pytest.raises(ValueError, match="must contain 'position' and 'rcs'"):
+        Scenario.from_dict(d)
+    d = ring_scenario_dict(2, 2); d["radars"][1].pop("pulse_compression_gain")
+    with pytest.raises(KeyError, match="Radar config 1 missing required parameter: pulse_compression_gain"):
+        Scenario.from_dict(d)
+    d = ring_scenario_dict(2, 2); d["radars"][0]["type_id"] = 7
+    with pytest.raises(ValueError, match="Radar config 0 invalid type_id"):
+        Scenario.from_dict(d)
+    d = ring_scenario_dict(2, 2); d["jammers"][0].pop("bj")
+    with pytest.raises(KeyError, match="Jammer config 0 missing required parameter: bj"):
+        Scenario.from_dict(d)
+    d = ring_scenario_dict(2, 2); d["jammers"][1]["colour"] = "red"
+    with pytest.raises(TypeError, match="unexpected keyword argument 'colour'"):
+        Scenario.from_dict(d)
+    d = ring_scenario_dict(2, 2); d["environment_params"]["rewards"]["rd_min"] = -0.5
+    capsys.readouterr()
+    Scenario.from_dict(d)
+    assert "rd_min (-0.5) should be less than rd_max" in capsys.readouterr().out
+
+
+def test_scenario_counts_follow_config_namespace():
+    """num_jammers/num_radars/episode_limit come from getattr(config, ...) with the YAML as default
+    (environment.py:82-84); main.py's namespace keeps them nested in env_args, so the YAML decides."""
+    d = ring_scenario_dict(3, 4)
+    sc = Scenario.from_dict(d, config=SimpleNamespace(env_args={"num_jammers": 2}))
+    assert (sc.num_jammers, sc.num_radars, sc.episode_limit) == (3, 4, 100)
+    sc = Scenario.from_dict(d, config=SimpleNamespace(num_jammers=2, num_radars=3, episode_limit=7))
+    assert (sc.num_jammers, sc.num_radars, sc.episode_limit, sc.n_actions, sc.state_dim) == (2, 3, 7, 7, 34)
+    with pytest.raises(ValueError):
+        Scenario.from_dict(d, config=SimpleNamespace(num_radars=9))
+
+
+def test_scenario_tables_known_answers():
+    """SURVEY.md section 8(c) known answers for the shipped 2j/2r scenario."""
+    sc, _ = load_scenario("2j2r_shipped")
+    t = sc.tables
+    assert t["radar_Ps"][0] == pytest.approx(3.3534683110189373e-10, rel=1e-15)
+    assert t["radar_Ps"][1] == pytest.approx(2.0120809866113628e-11, rel=1e-15)
+    assert t["radar_snr_no"][0] == pytest.approx(1.680715505856303e-05, rel=1e-15)
+    assert t["radar_pd_no"][0] == pytest.approx(0.10292951362832024, rel=1e-15)
+    assert t["radar_pd_no"][1] == pytest.approx(0.10292515026692867, rel=1e-15)
+    assert t["radar_Pn"][0] == pytest.approx(0.001995262314968879, rel=1e-15)
+    assert sc.pd_consts[0] == pytest.approx(13.337474757021274, rel=1e-15)
+    assert sc.pd_consts[1] == pytest.approx(0.6191433636703569, rel=1e-15)
+    assert sc.pd_consts[2] == pytest.approx(3.300496970842553, rel=1e-15)
+    # Prj(j0->r0, 50 W) = 0.7981049259875517: (50 * gj * gr) / denom
+    prj = (50.0 * t["jam_gj"][0] * t["radar_gr"][0]) / t["jr_denom"][0]
+    assert prj == pytest.approx(0.7981049259875517, rel=1e-15)
+
+
+def test_edge_scenario_flags():
+    sc, _ = load_scenario("3j3r_edge")
+    den = sc.tables["jr_denom"].reshape(3, 3)
+    flg = sc.tables["jr_flags"].reshape(3, 3)
+    assert den[0, 0] < 0            # jammer 0 sits on radar 0
+    assert flg[2, 2] == 1           # Python-float (weak) denominator
+    assert flg.sum() == 1 and (den[den >= 0] > 0).all()

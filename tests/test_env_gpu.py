@@ -1,0 +1,227 @@
+"""GPU parity tests of the HIP env-step kernel, called through the C-ABI (libmacjd_hip.so).
+
+Bar (BASELINE.json north_star): integer outputs (FSM / terminated / masks) bit-exact; float rewards
+within 1e-5 of the reference.  The float64 diagnostics are additionally held to 1e-9 relative, which
+documents how close the device arithmetic actually is (device exp() may differ from the host's in the
+last ulp)."""
+import numpy as np
+import pytest
+import torch
+
+from _harness import OracleEnv, load_scenario, random_actions
+
+pytestmark = pytest.mark.gpu
+
+SCENARIOS = ["2j2r_shipped", "3j4r", "6j8r", "12j16r", "3j3r_edge"]
+TOL_REWARD = 1e-5  # north_star tolerance on float rewards
+
+
+def _env(sc, E, **kw):
+    from macjd_amd.simulation.environment import BatchedElectromagneticEnvironment
+    return BatchedElectromagneticEnvironment(scenario=sc, batch_envs=E, device="cuda:0", **kw)
+
+
+def _diag(E, R, J):
+    z = lambda *s: torch.zeros(*s, dtype=torch.float64, device="cuda:0")
+    return {"out64": z(E, 4), "pd64": z(E, R), "snr64": z(E, R), "prj64": z(E, J)}
+
+
+def _cmp(o, rew, term, info, diag=None):
+    np.testing.assert_array_equal(info["radar_tracking"].cpu().numpy(), o["track"])
+    np.testing.assert_array_equal(term.cpu().numpy(), o["terminated"].astype(bool))
+    np.testing.assert_array_equal(info["step_count"].cpu().numpy(), o["step"])
+    np.testing.assert_allclose(rew.cpu().numpy(), o["reward"], rtol=0, atol=TOL_REWARD)
+    for i, k in enumerate(("r_d", "r_p", "r_j")):
+        np.testing.assert_allclose(info[k].cpu().numpy(), o["r_dpj"][:, i], rtol=0, atol=TOL_REWARD)
+    np.testing.assert_allclose(info["radar_pds"].cpu().numpy(), o["pd"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(info["snr_with_jamming"].cpu().numpy(), o["snr_with"], rtol=1e-6, atol=0)
+    if diag is not None:
+        np.testing.assert_allclose(diag["out64"].cpu().numpy(), o["out64"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(diag["pd64"].cpu().numpy(), o["pd64"], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(diag["snr64"].cpu().numpy(), o["snr64"], rtol=1e-13, atol=0)
+        np.testing.assert_allclose(diag["prj64"].cpu().numpy(), o["prj64"], rtol=1e-14, atol=0)
+
+
+@pytest.mark.parametrize("name", SCENARIOS)
+@pytest.mark.parametrize("mode", ["f32", "f64"])
+def test_golden_trace_single_env(name, mode):
+    """The reference's own traces (actions + logged MT19937 uniforms) through the HIP kernel, E=1."""
+    sc, g = load_scenario(name)
+    R, J = sc.num_radars, sc.num_jammers
+    env = _env(sc, 1)
+    diag = _diag(1, R, J)
+    for seed in (42, 43, 44):
+        pre = f"{mode}_s{seed}_"
+        T, P, U = g[pre + "T"], g[pre + "P"], g[pre + "u"]
+        Td = torch.from_numpy(T).cuda()
+        Pd = torch.from_numpy(P.astype(np.float32) if mode == "f32" else P).cuda()
+        Ud = torch.from_numpy(np.nan_to_num(U, nan=2.0)).cuda()
+        got = {k: [] for k in ("out", "pd", "snr", "prj", "track", "term")}
+        for t in range(T.shape[0]):
+            if g[pre + "reset_before"][t]:
+                env.reset()
+            _, term, info = env.step(Td[t:t + 1], Pd[t:t + 1], Ud[t:t + 1], diag=diag)
+            got["out"].append(diag["out64"].clone()); got["pd"].append(diag["pd64"].clone())
+            got["snr"].append(diag["snr64"].clone()); got["prj"].append(diag["prj64"].clone())
+            got["track"].append(info["radar_tracking"].clone()); got["term"].append(term.clone())
+        cat = lambda k: torch.cat(got[k]).cpu().numpy()
+        np.testing.assert_array_equal(cat("track"), g[pre + "track"])            # bit-exact FSM
+        np.testing.assert_array_equal(cat("term"), g[pre + "terminated"])
+        ref = np.stack([g[pre + "reward"], g[pre + "r_d"], g[pre + "r_p"], g[pre + "r_j"]], axis=1)
+        np.testing.assert_allclose(cat("out"), ref, rtol=0, atol=TOL_REWARD)     # the stated bar
+        np.testing.assert_allclose(cat("out"), ref, rtol=1e-9, atol=1e-12)       # what it actually achieves
+        np.testing.assert_allclose(cat("pd"), g[pre + "pd"], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(cat("snr"), g[pre + "snr_with"], rtol=1e-13, atol=0)
+        np.testing.assert_allclose(cat("prj"), g[pre + "prj"], rtol=1e-14, atol=0)
+
+
+@pytest.mark.parametrize("name", SCENARIOS)
+@pytest.mark.parametrize("E", [1, 63, 64, 65, 257, 4096])
+def test_batch_vs_oracle_supplied_uniforms(name, E):
+    sc, _ = load_scenario(name)
+    R, J = sc.num_radars, sc.num_jammers
+    env, ora = _env(sc, E), OracleEnv(sc, E, n_threads=4)
+    env.reset()
+    rng = np.random.default_rng(E * 7 + R)
+    diag = _diag(E, R, J)
+    for t in range(4):
+        T, P = random_actions(rng, E, J, R)
+        u = rng.random((E, R + J))
+        rew, term, info = env.step(torch.from_numpy(T).cuda(), torch.from_numpy(P).cuda(),
+                                   torch.from_numpy(u).cuda(), diag=diag)
+        _cmp(ora.step(T, P, u=u), rew, term, info, diag)
+
+
+@pytest.mark.parametrize("name", ["3j4r", "6j8r", "3j3r_edge"])
+def test_philox_mode_and_layouts(name):
+    """In-kernel Philox == oracle Philox; agent-major ([J,E]) action storage == env-major."""
+    sc, _ = load_scenario(name)
+    R, J, E = sc.num_radars, sc.num_jammers, 1000
+    env = _env(sc, E, seed=1234, env_offset=5000)
+    env2 = _env(sc, E, seed=1234, env_offset=5000)
+    ora = OracleEnv(sc, E, n_threads=4)
+    env.reset(); env2.reset()
+    rng = np.random.default_rng(3)
+    diag = _diag(E, R, J)
+    for t in range(6):
+        T, P = random_actions(rng, E, J, R)
+        o = ora.step(T, P, seed=1234, env_offset=5000)
+        rew, term, info = env.step(torch.from_numpy(T).cuda(), torch.from_numpy(P).cuda(), diag=diag)
+        _cmp(o, rew, term, info, diag)
+        # agent-major storage, passed as transposed views, int64 discrete actions with a trailing dim
+        T_am = torch.from_numpy(np.ascontiguousarray(T.T)).cuda().to(torch.int64)
+        P_am = torch.from_numpy(np.ascontiguousarray(P.T)).cuda()
+        rew2, term2, info2 = env2.step(T_am.t().unsqueeze(-1), P_am.t().unsqueeze(-1))
+        _cmp(o, rew2, term2, info2)
+
+
+def test_arith_modes():
+    """float64 power input, and float32 input with the ARITH_F64 flag, follow the oracle's f64 leg."""
+    sc, _ = load_scenario("3j3r_edge")
+    R, J, E = sc.num_radars, sc.num_jammers, 512
+    rng = np.random.default_rng(9)
+    T, P = random_actions(rng, E, J, R)
+    u = rng.random((E, R + J))
+    for variant in ("p64", "p32_flag"):
+        env, ora = _env(sc, E), OracleEnv(sc, E)
+        env.reset()
+        diag = _diag(E, R, J)
+        if variant == "p64":
+            P_in = P.astype(np.float64) + 1e-9
+            rew, term, info = env.step(torch.from_numpy(T).cuda(), torch.from_numpy(P_in).cuda(),
+                                       torch.from_numpy(u).cuda(), diag=diag)
+            o = ora.step(T, P_in, u=u)
+        else:
+            rew, term, info = env.step(torch.from_numpy(T).cuda(), torch.from_numpy(P).cuda(),
+                                       torch.from_numpy(u).cuda(), diag=diag, arith_f64=True)
+            o = ora.step(T, P, u=u, arith_f64=True)
+        _cmp(o, rew, term, info, diag)
+
+
+def test_full_size_properties():
+    """BASELINE.json sizes (E=4096 and 32768): size-independent properties + oracle spot check."""
+    sc, _ = load_scenario("3j4r")
+    R, J = sc.num_radars, sc.num_jammers
+    for E in (4096, 32768):
+        env = _env(sc, E, seed=42)
+        env.reset()
+        g = torch.Generator(device="cuda").manual_seed(1)
+        ret = torch.zeros(E, device="cuda")
+        for t in range(sc.episode_limit):
+            T = torch.randint(0, 2 * R + 1, (J, E), generator=g, device="cuda", dtype=torch.int32).t()
+            P = torch.rand((J, E), generator=g, device="cuda").t()
+            rew, term, info = env.step(T, P)
+            # reward decomposition and the closed form of r_p (environment.py:377): pmin=0 -> norm = P
+            tot = info["r_d"] + info["r_p"] + info["r_j"]
+            assert torch.allclose(rew, tot, atol=1e-6)
+            rp = (sc.rp_max + (sc.rp_min - sc.rp_max) * P.double()).sum(1)
+            assert torch.allclose(info["r_p"].double(), rp, atol=1e-6)
+            # r_d is a sum of per-radar penalties over the tracking radars
+            pen = torch.tensor(sc.tables["radar_rd_pen"], device="cuda")
+            assert torch.allclose(info["r_d"].double(), (info["radar_tracking"].double() * pen).sum(1), atol=1e-6)
+            assert bool(term.all()) == (t == sc.episode_limit - 1)
+            assert bool(term.any()) == (t == sc.episode_limit - 1)
+            ret += rew
+        assert torch.isfinite(ret).all()
+        # Pd floor: no suppression can push Pd below pd(0); tracking frequency ~ Pd
+        assert float(info["radar_pds"].min()) >= 0.1029
+        # idle jammers: r_j == 0 exactly, r_p == J * rp_max when P == 0
+        env.reset()
+        rew, term, info = env.step(torch.zeros((E, J), dtype=torch.int32, device="cuda"),
+                                   torch.zeros((E, J), device="cuda"))
+        assert float(info["r_j"].abs().max()) == 0.0
+        assert torch.allclose(info["r_p"], torch.full((E,), J * sc.rp_max, device="cuda"), atol=1e-7)
+
+
+def test_shard_invariance_and_determinism():
+    """Sharding envs over ranks (env_offset) does not change any env's trajectory; same seed twice is
+    bit-identical (multi-GPU row of SURVEY.md section 8e)."""
+    sc, _ = load_scenario("3j4r")
+    R, J, E = sc.num_radars, sc.num_jammers, 2048
+    rng = np.random.default_rng(2)
+    T, P = random_actions(rng, E, J, R)
+    Td, Pd = torch.from_numpy(T).cuda(), torch.from_numpy(P).cuda()
+    whole = _env(sc, E, seed=99)
+    lo, hi = _env(sc, E // 2, seed=99, env_offset=0), _env(sc, E // 2, seed=99, env_offset=E // 2)
+    again = _env(sc, E, seed=99)
+    for e in (whole, lo, hi, again):
+        e.reset()
+    for t in range(5):
+        r_w, _, i_w = whole.step(Td, Pd)
+        r_a, _, i_a = again.step(Td, Pd)
+        r_l, _, i_l = lo.step(Td[:E // 2], Pd[:E // 2])
+        r_h, _, i_h = hi.step(Td[E // 2:], Pd[E // 2:])
+        assert torch.equal(r_w, r_a) and torch.equal(i_w["radar_tracking"], i_a["radar_tracking"])
+        assert torch.equal(r_w, torch.cat([r_l, r_h]))
+        assert torch.equal(i_w["radar_tracking"], torch.cat([i_l["radar_tracking"], i_h["radar_tracking"]]))
+
+
+def test_reset_mask_and_outputs_into_caller_buffers():
+    sc, _ = load_scenario("3j4r")
+    R, J, E = sc.num_radars, sc.num_jammers, 300
+    env = _env(sc, E, seed=5)
+    env.reset()
+    T = torch.ones((E, J), dtype=torch.int32, device="cuda")
+    P = torch.full((E, J), 0.5, device="cuda")
+    rows = torch.zeros((4, E), device="cuda")
+    terms = torch.zeros((4, E), dtype=torch.uint8, device="cuda")
+    for t in range(4):
+        rew, term, _ = env.step(T, P, out_reward=rows[t], out_terminated=terms[t])
+        assert rew.data_ptr() == rows[t].data_ptr()
+    assert (rows != 0).any() and int(env.step_count.min()) == 4
+    mask = torch.zeros(E, dtype=torch.bool, device="cuda")
+    mask[::3] = True
+    env.reset(mask)
+    sc_ = env.step_count.cpu().numpy()
+    assert (sc_[::3] == 0).all() and (np.delete(sc_, np.arange(0, E, 3)) == 4).all()
+    assert int(env.track[::3].sum()) == 0
+
+
+def test_bad_arguments_raise():
+    sc, _ = load_scenario("3j4r")
+    env = _env(sc, 8)
+    with pytest.raises(ValueError):
+        env.step(torch.zeros((8, 2), dtype=torch.int32, device="cuda"), torch.zeros((8, 2), device="cuda"))
+    with pytest.raises(ValueError):
+        env.step(torch.zeros((8, 3), dtype=torch.int32, device="cuda"), torch.zeros((8, 3), device="cuda"),
+                 torch.zeros((8, 3), dtype=torch.float64, device="cuda"))
