@@ -1,0 +1,59 @@
+/*
+ * macjd_nets.h — C-ABI of the fused agent-side kernels in libmacjd_hip.so (MI355X / gfx950).
+ *
+ * The reference has no native layer; the interfaces replaced here are Python call sites:
+ *   macjd_qhead_select   BasicMAC.select_actions' multi-pass loop + mask + epsilon-greedy + gather
+ *                        (reference core/mac.py:109-164, utils/action_selectors.py:15-62) and the
+ *                        per-action loop of QMixLearner._get_all_action_q_values_and_params
+ *                        (core/qmix.py:256-274), both built on RNNAgent.get_q_value_for_action
+ *                        (core/networks.py:131-180);
+ *   macjd_gru_sequence   the learner's `for t in range(max_seq_len)` GRU unroll
+ *                        (core/qmix.py:241-253 -> core/networks.py:88-114);
+ *   macjd_mixer_forward  QMixer.forward after the hyper-network GEMMs (core/networks.py:283-315).
+ * Device pointers, element strides, no torch / HIP types; asynchronous on the given stream.
+ */
+#ifndef MACJD_NETS_H
+#define MACJD_NETS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/*
+ * Q(h, a, P[:,a]) for every discrete action a in one pass, optionally followed by availability
+ * masking, epsilon-greedy choice and the gather of the chosen power.
+ *
+ * The Q-head's first layer is W1 [H, H+A+1] applied to cat([h, onehot(a), P_a]) (networks.py:75-79,
+ * 171-174).  The caller supplies base = W1[:, :H] h + b1 (one GEMM, [N,H]); the kernel adds the
+ * action column W1[:, H+a] and the rank-1 power term W1[:, H+A] * P_a, applies ReLU and the second
+ * layer (w2, b2), for all a, without materialising [N, A, H].
+ * Row n of base / P_all / Q is (env e, agent j) with n = e * n_agents + j.
+ */
+typedef struct macjd_qhead_io {
+    int64_t n_rows;          /* N = E * n_agents */
+    int32_t H, A, n_agents, greedy_only; /* greedy_only != 0: test_mode (argmax, no exploration) */
+    const float* base;  int64_t base_ld;   /* [N,H] row stride in elements */
+    const float* P_all; int64_t p_ld;      /* [N,A] actor output (networks.py:116-129) */
+    const float* W1;    int64_t w1_ld;     /* fc2_q_head.0.weight [H, H+A+1], row stride */
+    const float* w2;                       /* fc2_q_head.2.weight [H] */
+    const float* b2;                       /* fc2_q_head.2.bias  [1] */
+    float* Q;           int64_t q_ld;      /* optional out [N,A]: UNMASKED Q-values */
+    /* ---- optional selection stage (T_out32 or T_out64 non-NULL) ---- */
+    const void* avail;  int32_t avail_elem_size, reserved; /* optional mask, int32 (4) or int64 (8) elements */
+    int64_t av_se, av_sj, av_sa;           /* avail element strides over (env, agent, action) */
+    float epsilon;      float reserved2;   /* exploration probability (action_selectors.py:30-32) */
+    uint64_t seed, counter;                /* Philox key / call counter for the exploration draws */
+    int32_t* T_out32;                      /* optional chosen action, int32 */
+    int64_t* T_out64;                      /* optional chosen action, int64 */
+    int64_t t32_se, t32_sj, t64_se, t64_sj;/* element strides over (env, agent) */
+    float* P_out;       int64_t po_se, po_sj; /* optional chosen power = P_all[n, T] (mac.py:151-164) */
+} macjd_qhead_io;
+
+int macjd_qhead_select(const macjd_qhead_io* io, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MACJD_NETS_H */

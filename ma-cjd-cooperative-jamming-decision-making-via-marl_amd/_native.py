@@ -20,6 +20,7 @@ EXPORTS = [
     "macjd_abi_version", "macjd_last_error", "macjd_device_count",
     "macjd_scenario_create", "macjd_scenario_destroy", "macjd_scenario_dims",
     "macjd_env_reset", "macjd_env_step", "macjd_env_step_timed",
+    "macjd_qhead_select",
 ]
 
 
@@ -42,6 +43,26 @@ class StepIO(ctypes.Structure):
         ("snr_with", ctypes.c_void_p), ("sw_se", ctypes.c_int64), ("sw_sx", ctypes.c_int64),
         ("out64", ctypes.c_void_p), ("pd64", ctypes.c_void_p), ("snr64", ctypes.c_void_p),
         ("prj64", ctypes.c_void_p),
+    ]
+
+
+class QheadIO(ctypes.Structure):
+    """ctypes mirror of ``macjd_qhead_io`` (include/macjd_nets.h)."""
+    _fields_ = [
+        ("n_rows", ctypes.c_int64),
+        ("H", ctypes.c_int32), ("A", ctypes.c_int32), ("n_agents", ctypes.c_int32), ("greedy_only", ctypes.c_int32),
+        ("base", ctypes.c_void_p), ("base_ld", ctypes.c_int64),
+        ("P_all", ctypes.c_void_p), ("p_ld", ctypes.c_int64),
+        ("W1", ctypes.c_void_p), ("w1_ld", ctypes.c_int64),
+        ("w2", ctypes.c_void_p), ("b2", ctypes.c_void_p),
+        ("Q", ctypes.c_void_p), ("q_ld", ctypes.c_int64),
+        ("avail", ctypes.c_void_p), ("avail_elem_size", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("av_se", ctypes.c_int64), ("av_sj", ctypes.c_int64), ("av_sa", ctypes.c_int64),
+        ("epsilon", ctypes.c_float), ("reserved2", ctypes.c_float),
+        ("seed", ctypes.c_uint64), ("counter", ctypes.c_uint64),
+        ("T_out32", ctypes.c_void_p), ("T_out64", ctypes.c_void_p),
+        ("t32_se", ctypes.c_int64), ("t32_sj", ctypes.c_int64), ("t64_se", ctypes.c_int64), ("t64_sj", ctypes.c_int64),
+        ("P_out", ctypes.c_void_p), ("po_se", ctypes.c_int64), ("po_sj", ctypes.c_int64),
     ]
 
 
@@ -78,6 +99,8 @@ def load() -> ctypes.CDLL:
     lib.macjd_env_step_timed.restype = ctypes.c_int
     lib.macjd_env_step_timed.argtypes = [ctypes.c_void_p, ctypes.POINTER(StepIO), ctypes.c_int, ctypes.c_void_p,
                                          ctypes.POINTER(ctypes.c_float)]
+    lib.macjd_qhead_select.restype = ctypes.c_int
+    lib.macjd_qhead_select.argtypes = [ctypes.POINTER(QheadIO), ctypes.c_void_p]
     if lib.macjd_abi_version() != ABI_VERSION:
         raise NativeLibraryError(f"{LIB_NAME}: ABI version {lib.macjd_abi_version()} != expected {ABI_VERSION}")
     _lib = lib

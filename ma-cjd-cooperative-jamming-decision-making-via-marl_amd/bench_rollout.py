@@ -1,0 +1,68 @@
+"""bench.py glue for the rollout / train modes: builds MAC + replay + learner + batched runner for the
+benchmark scenario and returns the per-step callable.
+
+One benchmark "step" = one batched environment step of E envs per GPU:
+  rollout  agent forward (fc1/GRU/actor GEMMs) + fused MP-DQN Q-head/epsilon-greedy kernel + env-step
+           kernel + staging writes; every episode_limit steps the E finished episodes move into the
+           device replay buffer (inside the timed region).
+  train    rollout step + ONE QMixLearner.train on a sampled batch of `batch_size` whole episodes
+           (reference cadence: train_interval = 1, i.e. one learner step per env step, main.py:212-216),
+           including the RCCL gradient all-reduce when world_size > 1.  The replay buffer is pre-filled
+           by one untimed rollout before warm-up so that sampling is valid from the first timed step.
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+
+def make_args(sc, hidden, device, batch_size=32, buffer_size=None, batch_envs=4096, seed=42):
+    info = sc.env_info()
+    return SimpleNamespace(
+        n_agents=info["n_agents"], n_actions=info["n_actions"], state_shape=info["state_shape"],
+        obs_shape=info["obs_shape"], episode_limit=info["episode_limit"], env_info=info,
+        rnn_hidden_dim=hidden, actor_hidden_dim=128, mixing_embed_dim=64, hyper_hidden_dim=128,
+        lr=5e-6, gamma=0.99, grad_norm_clip=1.0, target_update_interval=200, batch_size=batch_size,
+        buffer_size=buffer_size or 2 * batch_envs, epsilon_start=1.0, epsilon_finish=0.05, epsilon_anneal_time=100000,
+        device=str(device), use_cuda=True, seed=seed)
+
+
+def make_step(cli, sc, env, dev, rank, world, mode):
+    from .core.mac import BasicMAC
+    from .core.qmix import QMixLearner
+    from .runners.episode_runner import BatchedEpisodeRunner
+    from .utils.replay_buffer import EpisodeReplayBuffer
+
+    args = make_args(sc, cli.hidden, dev, batch_envs=env.batch_envs)
+    torch.manual_seed(42)  # identical initial weights on every rank
+    with contextlib.redirect_stdout(io.StringIO()):
+        mac = BasicMAC(args.obs_shape, args)
+        mac.select_seed = 42 + 1000 * rank
+        buf = EpisodeReplayBuffer(args, device=dev)
+        learner = QMixLearner(mac, args)
+    runner = BatchedEpisodeRunner(env, mac, buf, args)
+    T = args.episode_limit
+    np.random.seed(1234 + rank)  # replay sampling stream (np.random.choice, like the reference)
+    if mode == "train":
+        runner.run(test_mode=False, sync_stats=False)  # untimed pre-fill of the replay buffer
+    stats_acc = {"loss": torch.zeros((), device=dev), "n": 0}
+
+    def step_fn(i):
+        t = i % T
+        if t == 0:
+            runner.begin_episodes()
+        runner.step(t)
+        if t == T - 1:
+            runner.end_episodes()
+        if mode == "train":
+            st = learner.train(buf.sample(args.batch_size), None, sync_stats=False)
+            stats_acc["loss"] += st["loss"]
+            stats_acc["n"] += 1
+
+    extra = {"hidden": cli.hidden, "train_batch_episodes": args.batch_size if mode == "train" else 0,
+             "train_calls_per_step": 1 if mode == "train" else 0, "replay_capacity_episodes": args.buffer_size}
+    return step_fn, extra

@@ -1,0 +1,142 @@
+"""Agent and mixer networks for the MP-DQN / QMix hot path on MI355X.
+
+Same module tree and ``state_dict`` keys as the reference (core/networks.py:16-315) so checkpoints
+interchange (``agent.pth`` / ``qmix_net.pth``):
+
+  RNNAgent   actor.{0,2,4}.{weight,bias}  fc1.*  rnn.{weight_ih,weight_hh,bias_ih,bias_hh}
+             fc2_q_head.{0,2}.*
+  QMixer     state_norm.*  hyper_w_1.{0,2}.*  hyper_w_final.{0,2}.*  hyper_b_1.*  V.{0,2}.*
+
+What is different is HOW the hot calls are evaluated:
+
+* ``RNNAgent.q_values_all_actions`` computes Q(h, a, P_a) for ALL discrete actions in one pass.  The
+  reference runs the Q-head once per action on ``cat([h, onehot(a), P_a])`` (core/mac.py:115-135,
+  core/qmix.py:260-274): A x (full, one_hot, cat, Linear, ReLU, Linear).  The first layer is linear in
+  its input, so  W1 [h; onehot(a); P_a] + b1 = (W_h h + b1) + W_a[:, a] + w_p P_a : the H x H product is
+  done once and each action only adds a column and a rank-1 term.  On a HIP device the add/ReLU/dot
+  epilogue runs in one fused kernel (csrc/macjd_nets.hip) that never materialises the [N, A, H]
+  tensor; results match the per-action loop to ~1e-6 (different summation order).
+* ``QMixer.forward`` keeps the reference arithmetic (LayerNorm -> 4 hyper-networks -> clamp ->
+  bmm/ELU/bmm, core/networks.py:250-315) but evaluates the two tiny batched products as broadcast
+  multiplies + reductions instead of ``torch.bmm`` over [M,1,J]x[M,J,Em] matrices.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+class RNNAgent(nn.Module):
+    """Actor MLP + (fc1 -> GRUCell) + MP-DQN Q-head (reference core/networks.py:16-180)."""
+
+    def __init__(self, input_shape, args):
+        super().__init__()
+        self.args = args
+        self.n_actions = args.n_actions
+        self.input_shape = input_shape
+        self.rnn_hidden_dim = args.rnn_hidden_dim
+        self.actor_input_dim = input_shape
+        self.actor_hidden_dim = args.actor_hidden_dim
+        self.actor_output_dim = self.n_actions
+        self.actor = nn.Sequential(  # networks.py:54-61
+            nn.Linear(self.actor_input_dim, self.actor_hidden_dim), nn.ReLU(),
+            nn.Linear(self.actor_hidden_dim, self.actor_hidden_dim), nn.ReLU(),
+            nn.Linear(self.actor_hidden_dim, self.actor_output_dim), nn.Sigmoid())
+        self.fc1 = nn.Linear(self.input_shape, self.rnn_hidden_dim)  # networks.py:65-66
+        self.rnn = nn.GRUCell(self.rnn_hidden_dim, self.rnn_hidden_dim)
+        q_head_input_dim = self.rnn_hidden_dim + self.n_actions + 1  # networks.py:73-79
+        self.fc2_q_head = nn.Sequential(
+            nn.Linear(q_head_input_dim, self.rnn_hidden_dim), nn.ReLU(),
+            nn.Linear(self.rnn_hidden_dim, 1))
+
+    def init_hidden(self):
+        """zeros [1, H] on the parameters' device (networks.py:81-86)."""
+        return self.fc1.weight.new_zeros(1, self.rnn_hidden_dim)
+
+    def forward(self, agent_inputs, h_in):
+        """h' = GRUCell(ReLU(fc1 obs), h)  (networks.py:88-114)."""
+        x = F.relu(self.fc1(agent_inputs))
+        if h_in.device != x.device:
+            h_in = h_in.to(x.device)
+        return self.rnn(x.contiguous(), h_in.contiguous())
+
+    def actor_forward(self, inputs):
+        """Continuous parameter for EVERY discrete action, [N, A] in (0,1)  (networks.py:116-129)."""
+        return self.actor(inputs)
+
+    def get_q_value_for_action(self, hidden_state, discrete_action_index, continuous_param):
+        """Q(h, T, P) for one (action, parameter) per row (networks.py:131-180).  Differentiable; this
+        is the only path through which the learner's loss reaches the agent (core/qmix.py:161-184).
+        Evaluated without building the one-hot / concatenated input: W1[:, H + T] is gathered."""
+        n = hidden_state.shape[0]
+        idx = discrete_action_index.long()
+        if idx.dim() > 1 and idx.shape[1] == 1:
+            idx = idx.squeeze(1)
+        if idx.numel() and (torch.any(idx < 0) or torch.any(idx >= self.n_actions)):  # networks.py:157-158
+            raise IndexError(f"Action index out of bounds: {idx}, n_actions: {self.n_actions}")
+        if continuous_param.dim() == 1:
+            continuous_param = continuous_param.unsqueeze(1)
+        elif continuous_param.dim() > 2 or (continuous_param.dim() == 2 and continuous_param.shape[1] != 1):
+            try:
+                continuous_param = continuous_param.view(n, 1)
+            except RuntimeError:
+                raise ValueError(f"Unexpected continuous_param shape: {continuous_param.shape}, expected ({n}, 1)")
+        H = self.rnn_hidden_dim
+        l1, l2 = self.fc2_q_head[0], self.fc2_q_head[2]
+        w_h, w_a, w_p = l1.weight[:, :H], l1.weight[:, H:H + self.n_actions], l1.weight[:, H + self.n_actions]
+        pre = F.linear(hidden_state, w_h, l1.bias) + w_a.t()[idx] + continuous_param * w_p.unsqueeze(0)
+        return l2(F.relu(pre))
+
+    def q_values_all_actions(self, hidden_state, continuous_params_all):
+        """Q(h, a, P[:, a]) for all a at once, [N, A].  Inference path (no autograd): replaces the
+        reference's per-action loop (core/mac.py:115-135, core/qmix.py:260-274)."""
+        H = self.rnn_hidden_dim
+        l1, l2 = self.fc2_q_head[0], self.fc2_q_head[2]
+        w_h = l1.weight[:, :H]
+        base = F.linear(hidden_state, w_h, l1.bias)  # [N, H], the one H x H product
+        return ops.qhead_all_actions(base, continuous_params_all, l1.weight, l2.weight, l2.bias, H, self.n_actions)
+
+
+class QMixer(nn.Module):
+    """QMix monotonic mixer with clamped hyper-network outputs (reference core/networks.py:182-315)."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.n_agents = args.n_agents
+        self.state_dim = int(np.prod(args.state_shape))
+        self.embed_dim = args.mixing_embed_dim
+        self.hyper_hidden_dim = args.hyper_hidden_dim
+        self.state_norm = nn.LayerNorm(self.state_dim)  # networks.py:215
+        self.hyper_w_1 = nn.Sequential(  # networks.py:223-248
+            nn.Linear(self.state_dim, self.hyper_hidden_dim), nn.ReLU(),
+            nn.Linear(self.hyper_hidden_dim, self.n_agents * self.embed_dim))
+        self.hyper_w_final = nn.Sequential(
+            nn.Linear(self.state_dim, self.hyper_hidden_dim), nn.ReLU(),
+            nn.Linear(self.hyper_hidden_dim, self.embed_dim * 1))
+        self.hyper_b_1 = nn.Linear(self.state_dim, self.embed_dim)
+        self.V = nn.Sequential(
+            nn.Linear(self.state_dim, self.embed_dim), nn.ReLU(),
+            nn.Linear(self.embed_dim, 1))
+
+    def forward(self, agent_qs, states):
+        """Q_tot = ELU(q . clamp(W1(s),0,5) + clamp(b1(s),-5,5)) . clamp(Wf(s),0,5) + clamp(V(s),-5,5)
+        on the LayerNorm-ed state (networks.py:250-315; note clamp, not abs).  Output shape follows
+        the reference: [B, T, 1] for [B, T, J] inputs, [B, 1] for [B, J]."""
+        batch_size = agent_qs.size(0)
+        s = self.state_norm(states.reshape(-1, self.state_dim))
+        q = agent_qs.reshape(-1, self.n_agents, 1)
+        w1 = torch.clamp(self.hyper_w_1(s), min=0.0, max=5.0).view(-1, self.n_agents, self.embed_dim)
+        b1 = torch.clamp(self.hyper_b_1(s), min=-5.0, max=5.0)
+        w_final = torch.clamp(self.hyper_w_final(s), min=0.0, max=5.0)
+        v = torch.clamp(self.V(s), min=-5.0, max=5.0)
+        hidden = F.elu((q * w1).sum(dim=1) + b1)          # bmm([M,1,J],[M,J,Em]) + b1
+        y = (hidden * w_final).sum(dim=1, keepdim=True) + v  # bmm([M,1,Em],[M,Em,1]) + v
+        q_tot = y.view(batch_size, -1, 1)
+        if q_tot.shape[1] == 1:
+            q_tot = q_tot.squeeze(1)
+        return q_tot

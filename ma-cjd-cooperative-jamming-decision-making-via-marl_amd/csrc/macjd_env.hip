@@ -27,6 +27,7 @@
 #include <string.h>
 
 #include "../../include/macjd.h"
+#include "macjd_err.h"
 #include "macjd_philox.h"
 
 namespace macjd {
@@ -45,7 +46,7 @@ struct DevTables {
 };
 
 static thread_local char g_err[512] = "";
-static int set_err(int code, const char* fmt, const char* a = "") {
+int set_err(int code, const char* fmt, const char* a) {
     snprintf(g_err, sizeof(g_err), fmt, a);
     return code;
 }

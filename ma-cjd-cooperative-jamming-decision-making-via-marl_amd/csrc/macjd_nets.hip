@@ -1,0 +1,158 @@
+// macjd_nets.hip — fused agent-side kernels for MI355X (gfx950, wave64).  C-ABI: include/macjd_nets.h
+//
+// qhead_select_kernel: the MP-DQN multi-pass Q-head for ALL discrete actions in one pass, plus the
+// availability mask, epsilon-greedy choice and the gather of the chosen power.  Replaces the reference's
+// per-action Python loop (core/mac.py:115-164 / core/qmix.py:256-274 over
+// RNNAgent.get_q_value_for_action, core/networks.py:131-180): A x (full, one_hot, cat, Linear, ReLU,
+// Linear) launches become one launch and the [N, A, H] intermediate never exists.
+//
+// Mapping: one lane = one (env, agent) row.  The per-action columns W1[:, H+a], the power column
+// W1[:, H+A] and w2 are wave-uniform, so they arrive through scalar loads (s_load) and feed the VALU
+// as SGPR operands; the only vector memory traffic is the row's own base[H] (16-B loads), its P[A]
+// and the outputs.  The A accumulators live in registers (kernel templated on A).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/macjd.h"
+#include "../../include/macjd_nets.h"
+#include "macjd_err.h"
+#include "macjd_philox.h"
+
+namespace macjd {
+
+static int set_nets_err(int code, const char* msg) { return set_err(code, "%s", msg); }
+
+__device__ __forceinline__ bool avail_at(const macjd_qhead_io& io, int64_t e, int j, int a) {
+    if (!io.avail) return true;
+    const int64_t off = e * io.av_se + (int64_t)j * io.av_sj + (int64_t)a * io.av_sa;
+    return (io.avail_elem_size == 8) ? (((const int64_t*)io.avail)[off] != 0)
+                                     : (((const int32_t*)io.avail)[off] != 0);
+}
+
+template <int AT>
+__global__ void __launch_bounds__(256) qhead_select_kernel(const macjd_qhead_io io) {
+    constexpr int AMAX = AT ? AT : 64;
+    const int A = AT ? AT : io.A;
+    const int H = io.H;
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= io.n_rows) return;
+
+    float p[AMAX], acc[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) {
+        const bool live = AT || a < A;
+        p[a] = live ? io.P_all[n * io.p_ld + a] : 0.0f;
+        acc[a] = 0.0f;
+    }
+    const float* __restrict__ brow = io.base + n * io.base_ld;
+    const bool vec4 = ((io.base_ld & 3) == 0) && ((((uintptr_t)io.base) & 15) == 0);
+    for (int h0 = 0; h0 < H; h0 += 4) {
+        float b4[4];
+        if (vec4 && h0 + 4 <= H) {
+            const float4 v = *reinterpret_cast<const float4*>(brow + h0);
+            b4[0] = v.x; b4[1] = v.y; b4[2] = v.z; b4[3] = v.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) b4[k] = (h0 + k < H) ? brow[h0 + k] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int h = h0 + k;
+            if (h >= H) break;
+            // wave-uniform row of the first layer: [W_a[h][0..A-1], w_p[h]] is contiguous in W1
+            const float* __restrict__ wrow = io.W1 + (int64_t)h * io.w1_ld + H;
+            const float wp = wrow[A];
+            const float w2h = io.w2[h];
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) {
+                if (!AT && a >= A) break;
+                float t = b4[k] + wrow[a];        // (W_h h + b1)[h] + W1[h, H+a]
+                t = fmaf(p[a], wp, t);            // + W1[h, H+A] * P_a
+                t = fmaxf(t, 0.0f);               // ReLU (networks.py:77)
+                acc[a] = fmaf(t, w2h, acc[a]);    // second layer (networks.py:78)
+            }
+        }
+    }
+    const float b2 = io.b2[0];
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) {
+        if (!AT && a >= A) break;
+        acc[a] += b2;
+        if (io.Q) io.Q[n * io.q_ld + a] = acc[a];
+    }
+    if (!io.T_out32 && !io.T_out64) return;
+
+    // ---- mask, greedy argmax (first maximum), epsilon-greedy; mac.py:142-146, action_selectors.py:34-62
+    const int64_t e = n / io.n_agents;
+    const int j = (int)(n - e * io.n_agents);
+    int best = 0, n_avail = 0;
+    float bestq = -INFINITY;
+    uint64_t avail_bits = 0;
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) {
+        if (!AT && a >= A) break;
+        const bool av = avail_at(io, e, j, a);
+        avail_bits |= av ? (1ull << a) : 0ull;
+        n_avail += av ? 1 : 0;
+        const float q = av ? acc[a] : -INFINITY;
+        if (q > bestq) { bestq = q; best = a; }
+    }
+    int chosen = best;
+    if (!io.greedy_only && io.epsilon > 0.0f) {
+        const Philox4 r = philox4x32_10((uint32_t)n, (uint32_t)((uint64_t)n >> 32), (uint32_t)io.counter,
+                                        (uint32_t)(io.counter >> 32), (uint32_t)io.seed, (uint32_t)(io.seed >> 32));
+        const float u_pick = (float)(r.v[0] >> 8) * (1.0f / 16777216.0f);
+        if (u_pick < io.epsilon) {
+            // uniform over the available actions (torch.multinomial over the mask in the reference);
+            // with no action available the reference falls back to uniform over all of them
+            const int pool = n_avail > 0 ? n_avail : A;
+            int k = (int)(((uint64_t)r.v[1] * (uint64_t)pool) >> 32);
+            chosen = 0;
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) {
+                if (!AT && a >= A) break;
+                const bool av = (n_avail > 0) ? ((avail_bits >> a) & 1ull) : true;
+                if (av) { if (k == 0) chosen = a; --k; }
+            }
+        }
+    }
+    float pc = 0.0f;
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) pc = (a == chosen) ? p[a] : pc;
+    if (io.T_out32) io.T_out32[e * io.t32_se + (int64_t)j * io.t32_sj] = chosen;
+    if (io.T_out64) io.T_out64[e * io.t64_se + (int64_t)j * io.t64_sj] = chosen;
+    if (io.P_out) io.P_out[e * io.po_se + (int64_t)j * io.po_sj] = pc;
+}
+
+}  // namespace macjd
+
+extern "C" int macjd_qhead_select(const macjd_qhead_io* io, void* hip_stream) {
+    using namespace macjd;
+    if (!io) return set_nets_err(MACJD_EINVAL, "macjd_qhead_select: NULL io");
+    if (io->n_rows < 0 || io->H < 1 || io->A < 1 || io->A > 64 || io->n_agents < 1)
+        return set_nets_err(MACJD_EINVAL, "macjd_qhead_select: bad n_rows / H / A / n_agents (A <= 64)");
+    if (!io->base || !io->P_all || !io->W1 || !io->w2 || !io->b2)
+        return set_nets_err(MACJD_EINVAL, "macjd_qhead_select: NULL input");
+    if (!io->Q && !io->T_out32 && !io->T_out64)
+        return set_nets_err(MACJD_EINVAL, "macjd_qhead_select: no output requested");
+    if (io->avail && io->avail_elem_size != 4 && io->avail_elem_size != 8)
+        return set_nets_err(MACJD_EINVAL, "macjd_qhead_select: avail_elem_size must be 4 or 8");
+    if (io->n_rows == 0) return MACJD_OK;
+    // small batches: one wave per workgroup so the rows spread over more CUs
+    const int block = io->n_rows >= (1 << 16) ? 256 : 64;
+    const dim3 g((unsigned)((io->n_rows + block - 1) / block)), b(block);
+    hipStream_t s = (hipStream_t)hip_stream;
+    switch (io->A) {
+        case 5:  hipLaunchKernelGGL((qhead_select_kernel<5>), g, b, 0, s, *io); break;
+        case 7:  hipLaunchKernelGGL((qhead_select_kernel<7>), g, b, 0, s, *io); break;
+        case 9:  hipLaunchKernelGGL((qhead_select_kernel<9>), g, b, 0, s, *io); break;
+        case 17: hipLaunchKernelGGL((qhead_select_kernel<17>), g, b, 0, s, *io); break;
+        case 33: hipLaunchKernelGGL((qhead_select_kernel<33>), g, b, 0, s, *io); break;
+        default: hipLaunchKernelGGL((qhead_select_kernel<0>), g, b, 0, s, *io); break;
+    }
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
+    return MACJD_OK;
+}

@@ -1,0 +1,132 @@
+"""Tensor-level entry points of the fused HIP kernels (csrc/macjd_nets.hip, include/macjd_nets.h).
+
+Dispatch rule: tensors on a HIP device ALWAYS go through libmacjd_hip.so — if the library is missing
+the call raises (no silent eager substitute on the GPU, so a GPU run can never pass on a fallback).
+Host (CPU) tensors are evaluated with stock torch ops; that branch exists only because the reference's
+networks are device-agnostic (``main.py --device cpu``) and for the gloo multi-process tests — the
+environment step itself has no CPU branch at all.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import _native
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
+def _qhead_fill(io: _native.QheadIO, base, P_all, W1, w2, b2, H: int, A: int, n_agents: int):
+    io.n_rows, io.H, io.A, io.n_agents = base.shape[0], H, A, n_agents
+    io.base, io.base_ld = base.data_ptr(), base.stride(0)
+    io.P_all, io.p_ld = P_all.data_ptr(), P_all.stride(0)
+    io.W1, io.w1_ld = W1.data_ptr(), W1.stride(0)
+    io.w2, io.b2 = w2.data_ptr(), b2.data_ptr()
+
+
+def qhead_all_actions_reference(base, P_all, W1, w2, b2, H: int, A: int) -> torch.Tensor:
+    """Plain-torch evaluation of the decomposed Q-head, [N, A] (host tensors / numerics tests)."""
+    w_a = W1[:, H:H + A]            # [H, A]
+    w_p = W1[:, H + A]              # [H]
+    pre = base.unsqueeze(1) + w_a.t().unsqueeze(0) + P_all.unsqueeze(2) * w_p.view(1, 1, -1)  # [N, A, H]
+    return F.relu(pre) @ w2.reshape(-1) + b2.reshape(())
+
+
+def qhead_all_actions(base, P_all, W1, w2, b2, H: int, A: int) -> torch.Tensor:
+    """Q(h, a, P[:, a]) for all a, [N, A] float32.  ``base`` = W1[:, :H] h + b1 ([N, H])."""
+    if not base.is_cuda:
+        return qhead_all_actions_reference(base, P_all, W1, w2, b2, H, A)
+    lib = _native.load()
+    base, P_all, W1 = _f32c(base.detach()), _f32c(P_all.detach()), _f32c(W1.detach())
+    w2, b2 = w2.detach().reshape(-1).contiguous(), b2.detach().reshape(-1).contiguous()
+    Q = torch.empty((base.shape[0], A), dtype=torch.float32, device=base.device)
+    io = _native.QheadIO()
+    _qhead_fill(io, base, P_all, W1, w2, b2, H, A, 1)
+    io.Q, io.q_ld = Q.data_ptr(), Q.stride(0)
+    with torch.cuda.device(base.device):
+        _native.check(lib.macjd_qhead_select(ctypes.byref(io), _stream(base)), "macjd_qhead_select")
+    return Q
+
+
+def qhead_select(base, P_all, W1, w2, b2, H: int, A: int, n_agents: int, avail: Optional[torch.Tensor],
+                 epsilon: float, greedy_only: bool, seed: int, counter: int, want_q: bool = False
+                 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+    """Fused all-action Q + mask + epsilon-greedy + gather on a HIP device.
+
+    Returns ``(T64 [E, J, 1] int64, P [E, J, 1] float32, T32 [E, J] int32 view of agent-major
+    storage, Q [N, A] or None)``.  ``T32``/``P`` are written agent-major ([J, E] storage) so the
+    env-step kernel reads them fully coalesced; the returned tensors are transposed VIEWS with the
+    reference's logical shapes."""
+    if not base.is_cuda:
+        raise RuntimeError("qhead_select is the HIP path; host tensors use the selector in utils.action_selectors")
+    lib = _native.load()
+    N = base.shape[0]
+    E = N // n_agents
+    dev = base.device
+    base, P_all, W1 = _f32c(base.detach()), _f32c(P_all.detach()), _f32c(W1.detach())
+    w2, b2 = w2.detach().reshape(-1).contiguous(), b2.detach().reshape(-1).contiguous()
+    T32 = torch.empty((n_agents, E), dtype=torch.int32, device=dev)
+    T64 = torch.empty((E, n_agents, 1), dtype=torch.int64, device=dev)
+    P_am = torch.empty((n_agents, E), dtype=torch.float32, device=dev)
+    Q = torch.empty((N, A), dtype=torch.float32, device=dev) if want_q else None
+    io = _native.QheadIO()
+    _qhead_fill(io, base, P_all, W1, w2, b2, H, A, n_agents)
+    io.greedy_only = 1 if greedy_only else 0
+    if Q is not None:
+        io.Q, io.q_ld = Q.data_ptr(), Q.stride(0)
+    if avail is not None:
+        if avail.dtype not in (torch.int32, torch.int64):
+            avail = avail.to(torch.int32)
+        if avail.device != dev:
+            avail = avail.to(dev)
+        io.avail, io.avail_elem_size = avail.data_ptr(), avail.element_size()
+        io.av_se, io.av_sj, io.av_sa = avail.stride(0), avail.stride(1), avail.stride(2)
+    io.epsilon, io.seed, io.counter = float(epsilon), int(seed) & (2 ** 64 - 1), int(counter) & (2 ** 64 - 1)
+    io.T_out32, io.t32_se, io.t32_sj = T32.data_ptr(), 1, E
+    io.T_out64, io.t64_se, io.t64_sj = T64.data_ptr(), n_agents, 1
+    io.P_out, io.po_se, io.po_sj = P_am.data_ptr(), 1, E
+    with torch.cuda.device(dev):
+        _native.check(lib.macjd_qhead_select(ctypes.byref(io), _stream(base)), "macjd_qhead_select")
+    return T64, P_am.t().unsqueeze(-1), T32.t(), Q
+
+
+def gru_sequence_reference(gi: torch.Tensor, w_hh: torch.Tensor, b_hh: torch.Tensor,
+                           h0: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Step-by-step GRU recurrence with stock torch ops (host tensors / numerics tests).
+
+    gi = W_ih x_t + b_ih for every step, [B, T, J, 3H] (gate order r, z, n as torch.nn.GRUCell);
+    returns every post-update hidden state, [B, T, J, H]:  r = s(gi_r + gh_r), z = s(gi_z + gh_z),
+    n = tanh(gi_n + r * gh_n), h' = (h - n) * z + n, with gh = W_hh h + b_hh."""
+    B, T, J, H3 = gi.shape
+    H = H3 // 3
+    h = gi.new_zeros(B * J, H) if h0 is None else h0.reshape(B * J, H)
+    out = gi.new_empty(B, T, J, H)
+    for t in range(T):
+        g = gi[:, t].reshape(B * J, H3)
+        gh = F.linear(h, w_hh, b_hh)
+        r = torch.sigmoid(g[:, :H] + gh[:, :H])
+        z = torch.sigmoid(g[:, H:2 * H] + gh[:, H:2 * H])
+        n = torch.tanh(g[:, 2 * H:] + r * gh[:, 2 * H:])
+        h = (h - n) * z + n
+        out[:, t] = h.view(B, J, H)
+    return out
+
+
+def gru_sequence(gi: torch.Tensor, w_hh: torch.Tensor, b_hh: torch.Tensor,
+                 h0: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """All T steps of the GRU recurrence for B*J independent sequences (inference path of the learner's
+    unroll, reference core/qmix.py:241-253)."""
+    if gi.is_cuda and hasattr(_native, "GruIO"):
+        return _gru_sequence_hip(gi, w_hh, b_hh, h0)
+    return gru_sequence_reference(gi, w_hh, b_hh, h0)

@@ -1,0 +1,256 @@
+"""Rollout drivers (reference runners/episode_runner.py:9-277).
+
+``EpisodeRunner``        the reference's one-env / one-episode protocol, same constructor, ``run(test_mode)``
+                         return keys and buffer layout (including its quirks: the stored ``hidden_state`` is
+                         the POST-update h_t, and row ``T`` of the T+1 arrays stays zero when the episode
+                         fills ``episode_limit`` because ``EpisodeBatch.update_last`` is then a no-op,
+                         episode_runner.py:246-255).  Works with the drop-in single-env facade.
+``BatchedEpisodeRunner`` the hot path: E environments x episode_limit steps with every tensor resident in
+                         HBM and NO host synchronisation inside the step loop; one transposing copy per
+                         key moves the finished episodes into the replay buffer.
+"""
+from __future__ import annotations
+
+from functools import partial
+from typing import Dict
+
+import numpy as np
+import torch
+
+
+class EpisodeBatch:
+    """Per-episode staging arrays (episode_runner.py:184-277)."""
+
+    _T_PLUS_1 = ("state", "obs", "avail_actions", "hidden_state")
+
+    def __init__(self, args, max_seq_length, n_agents, obs_shape):
+        self.args = args
+        self.max_seq_length = max_seq_length
+        self.n_agents = n_agents
+        self.obs_shape = obs_shape
+        env_info = args.env_info
+        self.scheme = {  # episode_runner.py:197-209
+            "state": ((env_info["state_shape"],), None, np.float32),
+            "obs": ((obs_shape,), "agents", np.float32),
+            "actions_discrete": ((1,), "agents", np.int32),
+            "actions_continuous": ((1,), "agents", np.float32),
+            "avail_actions": ((env_info["n_actions"],), "agents", np.int64),
+            "reward": ((1,), None, np.float32),
+            "terminated": ((1,), None, np.bool_),
+            "hidden_state": ((args.rnn_hidden_dim,), "agents", np.float32),
+        }
+        self.data: Dict[str, np.ndarray] = {}
+        self.t = 0
+
+    def _init_data(self):
+        self.data = {}
+        for key, (vshape, group, dtype) in self.scheme.items():
+            seq = self.max_seq_length + 1 if key in self._T_PLUS_1 else self.max_seq_length
+            shape = (seq, self.n_agents) + tuple(vshape) if group == "agents" else (seq,) + tuple(vshape)
+            self.data[key] = np.zeros(shape, dtype=dtype)
+        self.t = 0
+
+    def push(self, transition_data):
+        if self.t == 0:
+            self._init_data()
+        if self.t < self.max_seq_length:
+            for key, value in transition_data.items():
+                if key in self.data:
+                    self.data[key][self.t] = value
+            self.t += 1
+        else:
+            print("Warning: Episode length exceeded max_seq_length. Data not stored.")
+
+    def update_last(self, last_data):
+        if self.t < self.max_seq_length:  # no-op for a full-length episode (episode_runner.py:252)
+            for key, value in last_data.items():
+                if key in self.data:
+                    self.data[key][self.t] = value
+
+    def get_batch_data(self):
+        out = {}
+        for key in self.scheme:
+            n = self.t + 1 if key in self._T_PLUS_1 else self.t
+            out[key] = [self.data[key][:n]]
+        return out
+
+
+class EpisodeRunner:
+    """One environment, one episode per ``run`` (episode_runner.py:9-181)."""
+
+    def __init__(self, env, mac, buffer, args):
+        self.env, self.mac, self.buffer, self.args = env, mac, buffer, args
+        env_info = self.env.get_env_info()
+        self.episode_limit = env_info["episode_limit"]
+        self.n_agents = env_info["n_agents"]
+        self.t = 0
+        self.t_env = 0
+        self.new_batch = partial(EpisodeBatch, self.args, self.episode_limit, self.n_agents, env_info["obs_shape"])
+        self.device = torch.device(args.device if torch.cuda.is_available() and args.use_cuda else "cpu")
+
+    def run(self, test_mode=False):
+        batch = self.new_batch()
+        self.mac.init_hidden(batch_size=1)
+        terminated, episode_return, step = False, 0, 0
+        rewards, r_d, r_p, r_j, ep_T, ep_P = [], [], [], [], [], []
+        self.env.reset()
+        state = self.env.get_state()
+        obs_list = self.env.get_obs()
+        info = {}
+        while not terminated:
+            obs_np = np.array(obs_list)
+            avail_np = np.array(self.env.get_avail_actions())
+            obs_t = torch.tensor(obs_np, dtype=torch.float32).unsqueeze(0).to(self.device)
+            avail_t = torch.tensor(avail_np, dtype=torch.long).unsqueeze(0).to(self.device)
+            T_t, P_t = self.mac.select_actions(obs_t, avail_t, self.t_env, test_mode=test_mode)
+            hidden_np = self.mac.hidden_states.detach().cpu().reshape(self.n_agents, -1).numpy()  # post-update h_t
+            T_np = T_t.detach().squeeze(0).cpu().numpy()
+            P_np = P_t.detach().squeeze(0).cpu().numpy()
+            ep_T.append(T_np)
+            ep_P.append(P_np)
+            next_obs_list, reward, terminated, info = self.env.step([(d[0], c[0]) for d, c in zip(T_np, P_np)])
+            rewards.append(reward)
+            r_d.append(info.get("r_d", 0)); r_p.append(info.get("r_p", 0)); r_j.append(info.get("r_j", 0))
+            episode_return += reward
+            batch.push({"state": np.array(state), "obs": obs_np, "actions_discrete": T_np,
+                        "actions_continuous": P_np, "avail_actions": avail_np, "reward": np.array([reward]),
+                        "terminated": np.array([terminated]), "hidden_state": hidden_np})
+            state = self.env.get_state()
+            obs_list = next_obs_list
+            step += 1
+            self.t_env += 1
+            if terminated or step >= self.episode_limit:
+                batch.update_last({"state": np.array(self.env.get_state()), "obs": np.array(next_obs_list),
+                                   "avail_actions": np.array(self.env.get_avail_actions())})
+                break
+        if not test_mode:
+            self.buffer.store_episode(batch.get_batch_data())
+
+        all_T = np.array(ep_T) if ep_T else np.empty((0, self.n_agents, 1))
+        all_P = np.array(ep_P) if ep_P else np.empty((0, self.n_agents, 1))
+        avg_power_per_agent = np.mean(all_P, axis=0).flatten() if all_P.size > 0 else np.zeros(self.n_agents)
+        counts = np.zeros(self.args.n_actions)
+        if all_T.size > 0:
+            counts = np.bincount(all_T.flatten().astype(int), minlength=self.args.n_actions)[:self.args.n_actions]
+        run_info = {
+            "episode_length": step,
+            "episode_return": episode_return,
+            "avg_step_reward": np.mean(rewards) if rewards else 0,
+            "avg_r_d": np.mean(r_d) if r_d else 0,
+            "avg_r_p": np.mean(r_p) if r_p else 0,
+            "avg_r_j": np.mean(r_j) if r_j else 0,
+            "avg_power_overall": np.mean(avg_power_per_agent),
+            "action_distribution": counts / max(1, np.sum(counts)),
+        }
+        if "individual_rewards" in info:
+            run_info["individual_rewards_final"] = info["individual_rewards"]
+        return run_info
+
+    def close_env(self):
+        self.env.close()
+
+
+class BatchedEpisodeRunner:
+    """E environments per rollout, device-resident, no per-step host sync.
+
+    Time-major staging tensors ``[T(+1), E, ...]`` make every per-step write a contiguous row, so the
+    env-step kernel writes reward / terminated straight into them; the action kernel's agent-major
+    outputs are copied in with one strided copy each.  The observation of this environment never
+    changes (reference simulation/environment.py:479-510 is a pure function of static parameters), so
+    when the env advertises ``observation_is_static`` the obs / state / avail rows are filled once.
+    """
+
+    def __init__(self, env, mac, buffer, args):
+        self.env, self.mac, self.buffer, self.args = env, mac, buffer, args
+        info = env.get_env_info()
+        self.episode_limit = info["episode_limit"]
+        self.n_agents = info["n_agents"]
+        self.batch_envs = env.batch_envs
+        self.device = env.device
+        self.t_env = 0  # env steps per environment, drives the epsilon schedule like the reference's counter
+        T, E, J = self.episode_limit, self.batch_envs, self.n_agents
+        S, A, H = info["state_shape"], info["n_actions"], args.rnn_hidden_dim
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=self.device)
+        self.stage = {
+            "state": z((T + 1, E, S), torch.float32), "obs": z((T + 1, E, J, S), torch.float32),
+            "avail_actions": z((T + 1, E, J, A), torch.int64), "hidden_state": z((T + 1, E, J, H), torch.float32),
+            "actions_discrete": z((T, E, J, 1), torch.int32), "actions_continuous": z((T, E, J, 1), torch.float32),
+            "reward": z((T, E, 1), torch.float32), "terminated": z((T, E, 1), torch.bool),
+        }
+        self._static = bool(getattr(env, "observation_is_static", False))
+        self._static_filled = False
+        self._rdpj_sum = z((E, 3), torch.float32)
+
+    def _fill_static(self):
+        T = self.episode_limit
+        self.stage["state"][:T] = self.env.get_state()
+        self.stage["obs"][:T] = self.env.get_obs()
+        self.stage["avail_actions"][:T] = self.env.get_avail_actions()
+        self._static_filled = True
+
+    def begin_episodes(self):
+        """Reset the E envs and the recurrent state; (re)fill static rows once."""
+        self.mac.init_hidden(batch_size=self.batch_envs)
+        self.env.reset()
+        if self._static and not self._static_filled:
+            self._fill_static()
+        self._rdpj_sum.zero_()
+        self._obs, self._avail = self.env.get_obs(), self.env.get_avail_actions()
+
+    def step(self, t, test_mode=False):
+        """Batched step t of the current episodes: agent forward + MP-DQN Q + epsilon-greedy (one fused
+        kernel), env-step kernel, staging writes.  Enqueues work only — no host synchronisation."""
+        env, mac, st = self.env, self.mac, self.stage
+        E, J = self.batch_envs, self.n_agents
+        if not self._static:
+            st["state"][t].copy_(env.get_state())
+            st["obs"][t].copy_(self._obs)
+            st["avail_actions"][t].copy_(self._avail)
+        T64, P_sel = mac.select_actions(self._obs, self._avail, self.t_env, test_mode=test_mode)
+        st["hidden_state"][t].copy_(mac.hidden_states.view(E, J, -1))  # post-update h_t
+        T32 = mac.last_actions_T32 if mac.last_actions_T32 is not None else T64.squeeze(-1).to(torch.int32)
+        st["actions_discrete"][t].copy_(T32.unsqueeze(-1))
+        st["actions_continuous"][t].copy_(P_sel)
+        env.step(T32, P_sel, out_reward=st["reward"][t].view(E), out_terminated=st["terminated"][t].view(E),
+                 want_info=False)
+        self._rdpj_sum += env._r_dpj
+        self.t_env += 1
+        if not self._static:
+            self._obs, self._avail = env.get_obs(), env.get_avail_actions()
+
+    def end_episodes(self, test_mode=False, store=True):
+        """Move the E finished episodes into the replay buffer (one transposing copy per key).  Row T of
+        the T+1 arrays stays zero for full-length episodes, as in the reference."""
+        if store and not test_mode:
+            self.buffer.store_episodes_batched(self.stage, self.batch_envs)
+
+    def run(self, test_mode=False, store=True, sync_stats=True):
+        """One batch of E episodes.  Returns the reference's ``run_info`` keys as means over the E
+        episodes (one host sync at the very end; pass ``sync_stats=False`` to get 0-dim tensors)."""
+        st = self.stage
+        T, E, J = self.episode_limit, self.batch_envs, self.n_agents
+        self.begin_episodes()
+        for t in range(T):
+            self.step(t, test_mode=test_mode)
+        self.end_episodes(test_mode=test_mode, store=store)
+        ret = st["reward"].sum(dim=(0, 2))  # [E]
+        stats = {
+            "episode_length": T,
+            "episode_return": ret.mean(),
+            "avg_step_reward": ret.mean() / T,
+            "avg_r_d": self._rdpj_sum[:, 0].mean() / T,
+            "avg_r_p": self._rdpj_sum[:, 1].mean() / T,
+            "avg_r_j": self._rdpj_sum[:, 2].mean() / T,
+            "avg_power_overall": st["actions_continuous"].mean(),
+            "action_distribution": torch.bincount(st["actions_discrete"].flatten().long(),
+                                                  minlength=self.args.n_actions)[:self.args.n_actions].float()
+            / float(T * E * J),
+            "n_episodes": E,
+        }
+        if sync_stats:
+            stats = {k: (v.item() if isinstance(v, torch.Tensor) and v.dim() == 0 else
+                         (v.cpu().numpy() if isinstance(v, torch.Tensor) else v)) for k, v in stats.items()}
+        return stats
+
+    def close_env(self):
+        self.env.close()

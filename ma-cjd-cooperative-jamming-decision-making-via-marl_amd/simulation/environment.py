@@ -58,6 +58,10 @@ class BatchedElectromagneticEnvironment:
     ``[J, E]`` tensor) gives fully coalesced loads.
     """
 
+    # The observation is a pure function of static scenario parameters (environment.py:479-510; nothing
+    # in step() moves an entity), so runners may fill their obs / state / avail rows once.
+    observation_is_static = True
+
     def __init__(self, config: Any = None, sim_config_path: str = DEFAULT_SIM_CONFIG_PATH,
                  batch_envs: Optional[int] = None, device=None, seed: Optional[int] = None,
                  env_offset: int = 0, scenario: Optional[Scenario] = None, verbose: bool = False):

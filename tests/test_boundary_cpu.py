@@ -33,7 +33,8 @@ def _write(d):
 
 
 def test_library_exports_every_declared_symbol(built):
-    hdr = open(os.path.join(REPO, "include", "macjd.h")).read()
+    inc = os.path.join(REPO, "include")
+    hdr = "\n".join(open(os.path.join(inc, f)).read() for f in sorted(os.listdir(inc)) if f.endswith(".h"))
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(macjd_[a-z_0-9]+)\s*\(", hdr))
     assert declared == set(_native.EXPORTS), declared ^ set(_native.EXPORTS)

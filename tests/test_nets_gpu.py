@@ -1,0 +1,265 @@
+"""GPU parity of the agent-side hot path: fused MP-DQN Q-head + selection kernel, MAC, mixer, learner,
+batched runner + device replay — through the C-ABI library, against the NumPy nets oracle and the
+reference-generated fixtures.  Tolerance on Q-values / Q_tot / hidden states: 1e-5 (BASELINE.json)."""
+import contextlib
+import io
+import json
+import os
+import sys
+import tempfile
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from _harness import GOLDEN, REPO, load_scenario
+
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+import nets_oracle  # noqa: E402
+
+from test_nets_cpu import load, make_args, quiet, sd_from  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+DEV = "cuda:0"
+
+
+def _gpu_args(d, **kw):
+    return make_args(d, device="cuda", use_cuda=True, **kw)
+
+
+@pytest.mark.parametrize("tag", ["3j4r_h64", "2j2r_h128", "6j8r_h64"])
+@pytest.mark.parametrize("N_envs", [5, 4096])
+def test_fused_qhead_vs_oracle(tag, N_envs):
+    """All-action Q (one launch) == the reference's per-action loop (oracle), incl. at rollout size."""
+    from macjd_amd import ops
+    from macjd_amd.core.networks import RNNAgent
+    g, d = load(tag)
+    agent = RNNAgent(d["S"], _gpu_args(d)).to(DEV)
+    agent.load_state_dict(sd_from(g, "agent."))
+    sdn = {k: v.cpu().numpy() for k, v in agent.state_dict().items()}
+    rng = np.random.default_rng(N_envs)
+    N = N_envs * d["J"]
+    h = (0.7 * rng.standard_normal((N, d["H"]))).astype(np.float32)
+    P = rng.random((N, d["A"])).astype(np.float32)
+    with torch.no_grad():
+        q = agent.q_values_all_actions(torch.from_numpy(h).to(DEV), torch.from_numpy(P).to(DEV))
+    q_ref = nets_oracle.q_all_actions(sdn, h, P)
+    np.testing.assert_allclose(q.cpu().numpy(), q_ref, atol=TOL, rtol=0)
+    # selection stage, greedy with a random availability mask: bit-exact actions wherever the top-2
+    # margin exceeds the float tolerance; chosen power is the gathered actor output
+    avail = (rng.random((N_envs, d["J"], d["A"])) < 0.7).astype(np.int64)
+    avail[..., 0] |= (avail.sum(-1) == 0)
+    l1, l2 = agent.fc2_q_head[0], agent.fc2_q_head[2]
+    with torch.no_grad():
+        base = torch.nn.functional.linear(torch.from_numpy(h).to(DEV), l1.weight[:, :d["H"]], l1.bias)
+        T64, Psel, T32, Q = ops.qhead_select(base, torch.from_numpy(P).to(DEV), l1.weight, l2.weight, l2.bias,
+                                             d["H"], d["A"], d["J"], torch.from_numpy(avail).to(DEV),
+                                             epsilon=0.0, greedy_only=True, seed=1, counter=1, want_q=True)
+    np.testing.assert_allclose(Q.cpu().numpy(), q_ref, atol=TOL, rtol=0)
+    T_ref, P_ref = nets_oracle.select_greedy(q_ref, P, avail.reshape(N, d["A"]))
+    qm = np.where(avail.reshape(N, -1) == 0, -np.inf, q_ref)
+    srt = np.sort(qm, axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 1e-4
+    got_T = T64.cpu().numpy().reshape(N)
+    np.testing.assert_array_equal(got_T[clear], T_ref[clear])
+    assert clear.mean() > 0.9
+    np.testing.assert_array_equal(T32.cpu().numpy().reshape(N), got_T)
+    np.testing.assert_array_equal(Psel.cpu().numpy().reshape(N), P[np.arange(N), got_T])
+    assert (avail.reshape(N, -1)[np.arange(N), got_T] == 1).all()
+
+
+def test_fused_selection_exploration_statistics():
+    """epsilon-greedy in-kernel: P(explore) ~ eps, uniform over AVAILABLE actions, deterministic per
+    (seed, counter), different across counters."""
+    from macjd_amd import ops
+    E, J, A, H = 20000, 3, 9, 64
+    base = torch.zeros(E * J, H, device=DEV)
+    P = torch.rand(E * J, A, device=DEV)
+    W1 = torch.zeros(H, H + A + 1, device=DEV)
+    W1[:, H + 4] = 1.0                       # action 4 is the greedy one
+    w2, b2 = torch.ones(1, H, device=DEV), torch.zeros(1, device=DEV)
+    avail = torch.ones(E, J, A, dtype=torch.int32, device=DEV)
+    avail[:, :, 7:] = 0
+    run = lambda eps, ctr: ops.qhead_select(base, P, W1, w2, b2, H, A, J, avail, epsilon=eps, greedy_only=False,
+                                            seed=3, counter=ctr)[0].view(-1)
+    t0 = run(0.0, 1)
+    assert (t0 == 4).all()
+    t1 = run(1.0, 1)
+    cnt = torch.bincount(t1, minlength=A).float() / t1.numel()
+    assert float(cnt[7:].sum()) == 0.0
+    assert float((cnt[:7] - 1 / 7).abs().max()) < 0.01
+    t3 = run(0.3, 2)
+    frac_not_greedy = float((t3 != 4).float().mean())
+    assert abs(frac_not_greedy - 0.3 * 6 / 7) < 0.01
+    assert torch.equal(t3, run(0.3, 2)) and not torch.equal(t3, run(0.3, 3))
+
+
+@pytest.mark.parametrize("tag", ["3j4r_h64", "2j2r_h128", "6j8r_h64"])
+def test_mac_on_gpu_matches_reference(tag):
+    """BasicMAC.select_actions(test_mode=True) on the HIP path vs the reference's outputs (G3)."""
+    from macjd_amd.core.mac import BasicMAC
+    g, d = load(tag)
+    mac = BasicMAC(d["S"], _gpu_args(d))
+    mac.load_state(sd_from(g, "agent."))
+    mac.cuda()
+    mac.init_hidden(5)
+    avail = torch.tensor(g["g3_sel_avail"]).to(DEV)
+    obs0 = torch.tensor(g["g3_obs"]).view(5, d["J"], d["S"]).to(DEV)
+    for t in range(3):
+        T_, P_ = mac.select_actions(obs0 * (1.0 + 0.1 * t), avail, t_env=t, test_mode=True)
+        assert T_.dtype == torch.int64 and T_.shape == (5, d["J"], 1) and P_.shape == (5, d["J"], 1)
+        np.testing.assert_array_equal(T_.cpu().numpy(), g["g3_sel_T"][t])
+        np.testing.assert_allclose(P_.cpu().numpy(), g["g3_sel_P"][t], atol=TOL, rtol=0)
+        np.testing.assert_allclose(mac.hidden_states.cpu().numpy(), g["g3_sel_h"][t], atol=TOL, rtol=0)
+        assert mac.last_actions_T32.dtype == torch.int32 and mac.last_actions_T32.stride() == (1, 5)
+
+
+@pytest.mark.parametrize("tag", ["3j4r_h64", "2j2r_h128"])
+def test_learner_on_gpu_matches_reference(tag):
+    """G5 on the device: stats within 1e-5 (relative to their scale), gradients, None-grad set."""
+    from macjd_amd.core.mac import BasicMAC
+    from macjd_amd.core.qmix import QMixLearner
+    g, d = load(tag)
+    args = _gpu_args(d)
+    with quiet():
+        mac = BasicMAC(d["S"], args)
+        mac.load_state(sd_from(g, "g5_agent0."))
+        learner = QMixLearner(mac, args)
+    learner.eval_qmix_net.load_state_dict(sd_from(g, "g5_mixer0."))
+    learner._update_targets()
+    assert next(mac.agent.parameters()).is_cuda
+    for step in range(3):
+        pre = f"g5_b{step}_"
+        batch = {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)}
+        batch["max_seq_len"] = int(batch["max_seq_len"])
+        stats = learner.train(batch, {})
+        got = np.array([stats["loss"], stats["grad_norm"], stats["eval_qtot_avg"], stats["target_qtot_avg"]])
+        np.testing.assert_allclose(got, g["g5_stats"][step], rtol=1e-4, atol=TOL)
+        named = {"agent." + n: p for n, p in mac.agent.named_parameters()}
+        named.update({"mixer." + n: p for n, p in learner.eval_qmix_net.named_parameters()})
+        none_ref = set(json.loads(str(g[f"g5_s{step}_grad_none_json"])))
+        assert {k for k, p in named.items() if p.grad is None} == none_ref
+        for k, p in named.items():
+            if k not in none_ref:
+                ref = g[f"g5_s{step}_grad.{k}"]
+                np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-3,
+                                           atol=2e-5 * max(1.0, float(np.abs(ref).max())))
+        for prefix, module in ((f"g5_s{step}_agent.", mac.agent), (f"g5_s{step}_tmixer.", learner.target_qmix_net)):
+            for k, v in sd_from(g, prefix).items():
+                np.testing.assert_allclose(module.state_dict()[k].cpu().numpy(), v.numpy(), atol=5e-6, rtol=0)
+
+
+def test_learner_unroll_on_gpu_vs_oracle_full_size():
+    """Reference batch shape (B=32 episodes x T=100, 3j/4r, H=64): the time-parallel unroll + GRU scan +
+    fused Q-head on the device == the per-step / per-action NumPy unroll."""
+    from macjd_amd.core.mac import BasicMAC
+    from macjd_amd.core.qmix import QMixLearner
+    g, d = load("3j4r_h64")
+    args = _gpu_args(d, episode_limit=100)
+    with quiet():
+        mac = BasicMAC(d["S"], args)
+        mac.load_state(sd_from(g, "agent."))
+        learner = QMixLearner(mac, args)
+    rng = np.random.default_rng(0)
+    B, T = 32, 100
+    obs = rng.standard_normal((B, T, d["J"], d["S"])).astype(np.float32)
+    q, _ = learner._get_all_action_q_values_and_params(mac, {"obs": obs}, T)
+    sdn = {k: v.cpu().numpy() for k, v in mac.agent.state_dict().items()}
+    h_all = nets_oracle.gru_unroll(sdn, obs)
+    p_ref = nets_oracle.actor_forward(sdn, obs.reshape(-1, d["S"]))
+    q_ref = nets_oracle.q_all_actions(sdn, h_all.reshape(-1, d["H"]), p_ref).reshape(B, T, d["J"], d["A"])
+    np.testing.assert_allclose(q.cpu().numpy(), q_ref, atol=TOL, rtol=0)
+    np.testing.assert_allclose(mac.hidden_states.cpu().numpy(), h_all[:, -1].reshape(-1, d["H"]), atol=TOL, rtol=0)
+
+
+def test_batched_runner_replay_learner_end_to_end():
+    """E=4096 x 100-step rollout with no per-step host sync, stored into the device replay, sampled and
+    trained on: shapes / dtypes / padding quirks of the reference's buffer, finite loss."""
+    from macjd_amd.core.mac import BasicMAC
+    from macjd_amd.core.qmix import QMixLearner
+    from macjd_amd.runners.episode_runner import BatchedEpisodeRunner
+    from macjd_amd.simulation.environment import BatchedElectromagneticEnvironment
+    from macjd_amd.utils.replay_buffer import EpisodeReplayBuffer
+    sc, _ = load_scenario("3j4r")
+    E = 4096
+    env = BatchedElectromagneticEnvironment(scenario=sc, batch_envs=E, device=DEV, seed=42)
+    info = env.get_env_info()
+    d = dict(J=info["n_agents"], A=info["n_actions"], S=info["state_shape"], H=64)
+    args = _gpu_args(d, episode_limit=info["episode_limit"], buffer_size=E + 100, batch_size=32, lr=5e-6,
+                     target_update_interval=200)
+    args.env_info = info
+    torch.manual_seed(42)
+    with quiet():
+        mac = BasicMAC(info["obs_shape"], args)
+        buf = EpisodeReplayBuffer(args)
+        learner = QMixLearner(mac, args)
+    runner = BatchedEpisodeRunner(env, mac, buf, args)
+    ri = runner.run(test_mode=False)
+    assert ri["episode_length"] == 100 and ri["n_episodes"] == E and np.isfinite(ri["episode_return"])
+    assert abs(ri["action_distribution"].sum() - 1.0) < 1e-5
+    assert ri["episode_return"] == pytest.approx(100 * (ri["avg_r_d"] + ri["avg_r_p"] + ri["avg_r_j"]), rel=1e-3)
+    assert buf.current_size == E and runner.t_env == 100
+    b = buf.buffers
+    assert b["filled"][:E].all() and not b["filled"][E:].any()
+    assert b["terminated"][:E, -1].all() and not b["terminated"][:E, :-1].any()
+    assert float(b["state"][:E, 100].abs().sum()) == 0.0           # zero row at index T (reference quirk)
+    assert float(b["hidden_state"][:E, 100].abs().sum()) == 0.0
+    np.testing.assert_array_equal(b["state"][7, 0].cpu().numpy(), sc.state_vector())
+    assert b["avail_actions"].dtype == torch.int64 and bool((b["avail_actions"][:E, :100] == 1).all())
+    assert int(b["actions_discrete"][:E].max()) <= 2 * sc.num_radars and int(b["actions_discrete"][:E].min()) >= 0
+    # the stored hidden state is the post-update h_t: row 0 equals one GRU step from zeros on the obs
+    with torch.no_grad():
+        h1 = mac.agent.forward(env.get_obs().reshape(-1, d["S"])[:3], torch.zeros(3, 64, device=DEV))
+    np.testing.assert_allclose(b["hidden_state"][0, 0].cpu().numpy(), h1.cpu().numpy(), atol=TOL)
+    # second rollout wraps the ring
+    runner.run(test_mode=False)
+    assert buf.current_size == E + 100 and buf.current_index == E - 100
+    np.random.seed(0)
+    for _ in range(3):
+        stats = learner.train(buf.sample(32), {})
+        assert all(np.isfinite(v) for v in stats.values())
+    assert learner.train_step == 3
+
+
+def test_reference_episode_end_to_end():
+    """The reference's own EpisodeRunner episode (seeded exploration, 2 episodes x 100 steps) reproduced by
+    the drop-in stack: facade env on the GPU + MAC on host tensors (same torch / NumPy RNG streams)."""
+    from macjd_amd.core.mac import BasicMAC
+    from macjd_amd.runners.episode_runner import EpisodeRunner
+    from macjd_amd.simulation.environment import ElectromagneticEnvironment
+    from macjd_amd.utils.replay_buffer import EpisodeReplayBuffer
+    g = np.load(os.path.join(GOLDEN, "episode_e2e.npz"))
+    a = json.loads(str(g["args_json"]))
+    path = os.path.join(tempfile.mkdtemp(prefix="macjd_e2e_"), "s.yaml")
+    with open(path, "w") as f:
+        yaml.safe_dump(json.loads(str(g["scenario_json"])), f)
+    args = SimpleNamespace(**a)
+    np.random.seed(42)
+    torch.manual_seed(42)
+    with quiet():
+        env = ElectromagneticEnvironment(args, path)
+        args.env_info = env.get_env_info()
+        mac = BasicMAC(args.obs_shape, args)
+        buf = EpisodeReplayBuffer(args, device="cpu")
+        runner = EpisodeRunner(env, mac, buf, args)
+    for k, v in sd_from(g, "agent.").items():   # same seed -> same default init as the reference
+        assert torch.equal(mac.agent.state_dict()[k], v), k
+    with quiet():
+        infos = [runner.run(test_mode=False) for _ in range(2)]
+    for ep, ri in enumerate(infos):
+        assert ri["episode_length"] == int(g[f"ep{ep}_episode_length"])
+        for k in ("episode_return", "avg_step_reward", "avg_r_d", "avg_r_p", "avg_r_j", "avg_power_overall"):
+            assert ri[k] == pytest.approx(float(g[f"ep{ep}_{k}"]), rel=1e-6, abs=1e-6), (ep, k)
+        np.testing.assert_allclose(ri["action_distribution"], g[f"ep{ep}_action_distribution"], atol=1e-12)
+    for k, v in buf.buffers.items():
+        ref = g[f"buffer_{k}"]
+        got = v[:2].numpy()
+        if got.dtype.kind in "iub":
+            np.testing.assert_array_equal(got, ref, err_msg=k)     # actions, masks, terminated, filled: bit-exact
+        else:
+            np.testing.assert_allclose(got, ref, atol=TOL, rtol=0, err_msg=k)
+    assert mac.action_selector.epsilon == pytest.approx(float(g["epsilon_after"]))
+    assert runner.t_env == int(g["t_env_after"])
