@@ -8,8 +8,7 @@
  *                        (core/qmix.py:256-274), both built on RNNAgent.get_q_value_for_action
  *                        (core/networks.py:131-180);
  *   macjd_gru_sequence   the learner's `for t in range(max_seq_len)` GRU unroll
- *                        (core/qmix.py:241-253 -> core/networks.py:88-114);
- *   macjd_mixer_forward  QMixer.forward after the hyper-network GEMMs (core/networks.py:283-315).
+ *                        (core/qmix.py:241-253 -> core/networks.py:88-114).
  * Device pointers, element strides, no torch / HIP types; asynchronous on the given stream.
  */
 #ifndef MACJD_NETS_H
@@ -52,6 +51,28 @@ typedef struct macjd_qhead_io {
 } macjd_qhead_io;
 
 int macjd_qhead_select(const macjd_qhead_io* io, void* hip_stream);
+
+/*
+ * All T steps of the GRU recurrence for B*J independent sequences, for up to two networks (eval and
+ * target) in one launch.  Replaces the learner's `for t in range(max_seq_len): h = agent.forward(...)`
+ * unroll (reference core/qmix.py:241-253 -> core/networks.py:88-114 -> torch.nn.GRUCell), inference
+ * only (the reference never back-propagates through it, see SURVEY.md section 8a note 4).
+ *
+ * gi = W_ih x_t + b_ih is time-parallel and supplied by the caller for every step ([B,T,J,3H],
+ * contiguous, gate order r,z,n); the kernel evaluates  gh = W_hh h + b_hh,  r = s(gi_r + gh_r),
+ * z = s(gi_z + gh_z),  n = tanh(gi_n + r * gh_n),  h' = (h - n) z + n  and stores every h' ([B,T,J,H]).
+ * H must be 64 or 128.
+ */
+typedef struct macjd_gru_io {
+    int32_t n_nets, B, T, J, H, reserved;   /* n_nets = 1 or 2 */
+    const float* gi[2];    /* [B,T,J,3H] */
+    const float* w_hh[2];  /* rnn.weight_hh [3H,H] row-major */
+    const float* b_hh[2];  /* rnn.bias_hh [3H] */
+    const float* h0[2];    /* optional initial state [B*J,H]; NULL = zeros (mac.init_hidden) */
+    float* h_out[2];       /* [B,T,J,H] */
+} macjd_gru_io;
+
+int macjd_gru_sequence(const macjd_gru_io* io, void* hip_stream);
 
 #ifdef __cplusplus
 }

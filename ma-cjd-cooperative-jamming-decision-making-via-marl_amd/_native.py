@@ -20,7 +20,7 @@ EXPORTS = [
     "macjd_abi_version", "macjd_last_error", "macjd_device_count",
     "macjd_scenario_create", "macjd_scenario_destroy", "macjd_scenario_dims",
     "macjd_env_reset", "macjd_env_step", "macjd_env_step_timed",
-    "macjd_qhead_select",
+    "macjd_qhead_select", "macjd_gru_sequence",
 ]
 
 
@@ -66,6 +66,16 @@ class QheadIO(ctypes.Structure):
     ]
 
 
+class GruIO(ctypes.Structure):
+    """ctypes mirror of ``macjd_gru_io`` (include/macjd_nets.h)."""
+    _fields_ = [
+        ("n_nets", ctypes.c_int32), ("B", ctypes.c_int32), ("T", ctypes.c_int32), ("J", ctypes.c_int32),
+        ("H", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("gi", ctypes.c_void_p * 2), ("w_hh", ctypes.c_void_p * 2), ("b_hh", ctypes.c_void_p * 2),
+        ("h0", ctypes.c_void_p * 2), ("h_out", ctypes.c_void_p * 2),
+    ]
+
+
 _lib: Optional[ctypes.CDLL] = None
 
 
@@ -101,6 +111,8 @@ def load() -> ctypes.CDLL:
                                          ctypes.POINTER(ctypes.c_float)]
     lib.macjd_qhead_select.restype = ctypes.c_int
     lib.macjd_qhead_select.argtypes = [ctypes.POINTER(QheadIO), ctypes.c_void_p]
+    lib.macjd_gru_sequence.restype = ctypes.c_int
+    lib.macjd_gru_sequence.argtypes = [ctypes.POINTER(GruIO), ctypes.c_void_p]
     if lib.macjd_abi_version() != ABI_VERSION:
         raise NativeLibraryError(f"{LIB_NAME}: ABI version {lib.macjd_abi_version()} != expected {ABI_VERSION}")
     _lib = lib

@@ -88,7 +88,10 @@ class RNNAgent(nn.Module):
         H = self.rnn_hidden_dim
         l1, l2 = self.fc2_q_head[0], self.fc2_q_head[2]
         w_h, w_a, w_p = l1.weight[:, :H], l1.weight[:, H:H + self.n_actions], l1.weight[:, H + self.n_actions]
-        pre = F.linear(hidden_state, w_h, l1.bias) + w_a.t()[idx] + continuous_param * w_p.unsqueeze(0)
+        # action column as a one-hot GEMM (not an index gather: the gather's backward is a serialised
+        # scatter-add over ~10^4 rows into A columns; as a GEMM both directions are dense products)
+        onehot = F.one_hot(idx, num_classes=self.n_actions).to(hidden_state.dtype)
+        pre = F.linear(hidden_state, w_h, l1.bias) + F.linear(onehot, w_a) + continuous_param * w_p.unsqueeze(0)
         return l2(F.relu(pre))
 
     def q_values_all_actions(self, hidden_state, continuous_params_all):

@@ -110,9 +110,13 @@ class QMixLearner:
         B = states.shape[0]
 
         # ---- all-action Q for target and eval networks (inference only), qmix.py:129-134 ----
+        # The reference's unroll leaves the ROLLOUT controller's hidden state at the sampled batch's
+        # h_T (qmix.py:241,253); it only trains between episodes so nothing reads it.  Here training
+        # may interleave with a running batched rollout, so the rollout state is put back.
+        rollout_hidden = self.mac.hidden_states
         with torch.no_grad():
-            target_q_all = self._all_action_q(self.target_mac, obs)   # [B, T, J, A]
-            eval_q_all = self._all_action_q(self.mac, obs)
+            target_q_all, eval_q_all = self._all_action_q_multi([self.target_mac, self.mac], obs)  # [B, T, J, A]
+            self.mac.hidden_states = rollout_hidden
             next_actions = eval_q_all[:, 1:].argmax(dim=3, keepdim=True)            # qmix.py:138-143 (no mask)
             target_q_taken = torch.gather(target_q_all[:, 1:], 3, next_actions).squeeze(3)  # qmix.py:147
             target_q_mixer = self.target_qmix_net(target_q_taken, states[:, 1:])    # qmix.py:151
@@ -156,23 +160,35 @@ class QMixLearner:
             stats = dict(zip(stats.keys(), vals))
         return stats
 
-    def _all_action_q(self, mac_controller, obs):
-        """Q(s_t, a, P_a(s_t)) for every discrete action, [B, T, J, A]; replaces the per-step /
-        per-action unroll of qmix.py:217-280 (the discarded ``params`` tensor is not built).  Leaves
-        ``mac_controller.hidden_states`` at the final h_T like the reference's loop does."""
-        agent = mac_controller.agent
+    def _all_action_q_multi(self, macs, obs):
+        """Q(s_t, a, P_a(s_t)) for every discrete action, [B, T, J, A] per controller; replaces the
+        per-step / per-action unroll of qmix.py:217-280 (the discarded ``params`` tensor is not built).
+        Everything but the recurrence is time-parallel: one GEMM each for fc1, the GRU input transform,
+        the actor layers and the Q-head base over all B*T*J rows; the recurrences of all controllers
+        (eval + target) run in ONE fused scan launch.  Leaves each controller's ``hidden_states`` at the
+        final h_T like the reference's loop does."""
         B, T, J, S = obs.shape
-        H, A = agent.rnn_hidden_dim, agent.n_actions
         rows = obs.reshape(B * T * J, S)
-        x = F.relu(agent.fc1(rows))                                        # time-parallel, networks.py:100
-        gi = F.linear(x, agent.rnn.weight_ih, agent.rnn.bias_ih).view(B, T, J, 3 * H)
-        h_all = ops.gru_sequence(gi, agent.rnn.weight_hh, agent.rnn.bias_hh)  # [B, T, J, H], h_0 = 0 (qmix.py:241)
-        mac_controller.hidden_states = h_all[:, T - 1].reshape(B * J, H) if T > 0 else None
-        params_all = agent.actor(rows)                                      # networks.py:127
-        l1, l2 = agent.fc2_q_head[0], agent.fc2_q_head[2]
-        base = F.linear(h_all.reshape(B * T * J, H), l1.weight[:, :H], l1.bias)
-        q = ops.qhead_all_actions(base, params_all, l1.weight, l2.weight, l2.bias, H, A)
-        return q.view(B, T, J, A)
+        gis = []
+        for m in macs:
+            a = m.agent
+            x = F.relu(a.fc1(rows))                                          # networks.py:100
+            gis.append(F.linear(x, a.rnn.weight_ih, a.rnn.bias_ih).view(B, T, J, 3 * a.rnn_hidden_dim))
+        h_alls = ops.gru_sequence_multi(gis, [m.agent.rnn.weight_hh for m in macs],
+                                        [m.agent.rnn.bias_hh for m in macs])  # h_0 = 0 (qmix.py:241)
+        out = []
+        for m, h_all in zip(macs, h_alls):
+            a = m.agent
+            H, A = a.rnn_hidden_dim, a.n_actions
+            m.hidden_states = h_all[:, T - 1].reshape(B * J, H) if T > 0 else None
+            params_all = a.actor(rows)                                       # networks.py:127
+            l1, l2 = a.fc2_q_head[0], a.fc2_q_head[2]
+            base = F.linear(h_all.reshape(B * T * J, H), l1.weight[:, :H], l1.bias)
+            out.append(ops.qhead_all_actions(base, params_all, l1.weight, l2.weight, l2.bias, H, A).view(B, T, J, A))
+        return out
+
+    def _all_action_q(self, mac_controller, obs):
+        return self._all_action_q_multi([mac_controller], obs)[0]
 
     def _get_all_action_q_values_and_params(self, mac_controller, batch, max_seq_len):
         """Reference-named entry (qmix.py:217-280): returns (Q [B,T,J,A], params [B,T,J,A])."""

@@ -156,3 +156,149 @@ extern "C" int macjd_qhead_select(const macjd_qhead_io* io, void* hip_stream) {
     if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
     return MACJD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// GRU sequence scan (learner unroll, inference only).
+//
+// One workgroup = one sequence (b, j) of one network; NW waves, one per SIMD.  The recurrence is a
+// 3H x H mat-vec per step, strictly sequential in t, so the design minimises the per-step latency and
+// spreads the B*J (x2 networks) independent sequences over as many CUs as there are sequences:
+//   * lane l owns hidden units u = l + 64 i (i < H/64), in every wave (the gate math is replicated, so
+//     every wave holds the complete new h in registers and no second barrier / broadcast is needed);
+//   * wave w owns the K-slice k in [w KW, (w+1) KW) of the mat-vec: its 3 U KW weights W_hh[g H + u][k]
+//     stay in VGPRs for all T steps; h[k] is pulled from the owning lane with v_readlane (wave-uniform
+//     SGPR operand of the FMA);
+//   * the NW partial sums per (gate, unit) meet in a double-buffered LDS tile, one barrier per step,
+//     and are added in fixed wave order (deterministic);
+//   * gi for step t+1 is loaded while step t computes; wave 0 stores h' (256-B coalesced rows).
+namespace macjd {
+
+template <int H, int NW>
+__global__ void __launch_bounds__(64 * NW) gru_sequence_kernel(const macjd_gru_io io) {
+    constexpr int U = H / 64;    // hidden units per lane
+    constexpr int KW = H / NW;   // K-slice per wave
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int net = blockIdx.y;
+    const int seq = blockIdx.x;  // b * J + j
+    const int b = seq / io.J, j = seq - b * io.J;
+    const int T = io.T;
+    const float* __restrict__ gi = io.gi[net];
+    const float* __restrict__ whh = io.w_hh[net];
+    const float* __restrict__ bhh = io.b_hh[net];
+    float* __restrict__ out = io.h_out[net];
+
+    __shared__ float s_part[2][NW][3][H];
+
+    // weights of this wave's K-slice, resident for the whole sequence
+    float w[3][U][KW];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const float* row = whh + (int64_t)(g * H + lane + 64 * i) * H + wave * KW;
+#pragma unroll
+            for (int kk = 0; kk < KW; kk += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(row + kk);
+                w[g][i][kk] = v.x; w[g][i][kk + 1] = v.y; w[g][i][kk + 2] = v.z; w[g][i][kk + 3] = v.w;
+            }
+        }
+    float bias[3][U], h[U], gcur[3][U], gnext[3][U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int u = lane + 64 * i;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) bias[g][i] = bhh[g * H + u];
+        h[i] = io.h0[net] ? io.h0[net][(int64_t)seq * H + u] : 0.0f;
+    }
+    auto gi_row = [&](int t) { return gi + (((int64_t)b * T + t) * io.J + j) * (3 * H); };
+    if (T > 0) {
+        const float* r0 = gi_row(0);
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int i = 0; i < U; ++i) gcur[g][i] = r0[g * H + lane + 64 * i];
+    }
+
+    for (int t = 0; t < T; ++t) {
+        if (t + 1 < T) {  // prefetch the next step's input transform (independent of the recurrence)
+            const float* rn = gi_row(t + 1);
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int i = 0; i < U; ++i) gnext[g][i] = rn[g * H + lane + 64 * i];
+        }
+        float acc[3][U];
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int i = 0; i < U; ++i) acc[g][i] = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < KW; ++kk) {
+            const int k = wave * KW + kk;  // wave-uniform
+            float hk;  // h[k], broadcast from its owning lane (k is wave-uniform -> SGPR lane select)
+            if constexpr (U == 1) {
+                hk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h[0]), k));
+            } else {
+                const float src = (k < 64) ? h[0] : h[U - 1];
+                hk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(src), k & 63));
+            }
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int i = 0; i < U; ++i) acc[g][i] = fmaf(w[g][i][kk], hk, acc[g][i]);
+        }
+        const int buf = t & 1;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int i = 0; i < U; ++i) s_part[buf][wave][g][lane + 64 * i] = acc[g][i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const int u = lane + 64 * i;
+            float gh[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                float s = 0.0f;
+#pragma unroll
+                for (int ww = 0; ww < NW; ++ww) s += s_part[buf][ww][g][u];
+                gh[g] = s + bias[g][i];
+            }
+            const float r = 1.0f / (1.0f + expf(-(gcur[0][i] + gh[0])));
+            const float z = 1.0f / (1.0f + expf(-(gcur[1][i] + gh[1])));
+            const float n = tanhf(gcur[2][i] + r * gh[2]);
+            h[i] = (h[i] - n) * z + n;
+        }
+        if (wave == 0) {
+            float* orow = out + (((int64_t)b * T + t) * io.J + j) * H;
+#pragma unroll
+            for (int i = 0; i < U; ++i) orow[lane + 64 * i] = h[i];
+        }
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int i = 0; i < U; ++i) gcur[g][i] = gnext[g][i];
+    }
+}
+
+}  // namespace macjd
+
+extern "C" int macjd_gru_sequence(const macjd_gru_io* io, void* hip_stream) {
+    using namespace macjd;
+    if (!io) return set_nets_err(MACJD_EINVAL, "macjd_gru_sequence: NULL io");
+    if (io->n_nets < 1 || io->n_nets > 2 || io->B < 0 || io->T < 0 || io->J < 1)
+        return set_nets_err(MACJD_EINVAL, "macjd_gru_sequence: bad n_nets / B / T / J");
+    if (io->H != 64 && io->H != 128) return set_nets_err(MACJD_EUNSUPPORTED, "macjd_gru_sequence: H must be 64 or 128");
+    for (int n = 0; n < io->n_nets; ++n)
+        if (!io->gi[n] || !io->w_hh[n] || !io->b_hh[n] || !io->h_out[n])
+            return set_nets_err(MACJD_EINVAL, "macjd_gru_sequence: NULL pointer");
+    if (io->B == 0 || io->T == 0) return MACJD_OK;
+    const dim3 g((unsigned)(io->B * io->J), (unsigned)io->n_nets);
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (io->H == 64) hipLaunchKernelGGL((gru_sequence_kernel<64, 4>), g, dim3(256), 0, s, *io);
+    else hipLaunchKernelGGL((gru_sequence_kernel<128, 8>), g, dim3(512), 0, s, *io);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
+    return MACJD_OK;
+}

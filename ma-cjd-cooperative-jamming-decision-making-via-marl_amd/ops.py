@@ -126,7 +126,42 @@ def gru_sequence_reference(gi: torch.Tensor, w_hh: torch.Tensor, b_hh: torch.Ten
 def gru_sequence(gi: torch.Tensor, w_hh: torch.Tensor, b_hh: torch.Tensor,
                  h0: Optional[torch.Tensor] = None) -> torch.Tensor:
     """All T steps of the GRU recurrence for B*J independent sequences (inference path of the learner's
-    unroll, reference core/qmix.py:241-253)."""
-    if gi.is_cuda and hasattr(_native, "GruIO"):
-        return _gru_sequence_hip(gi, w_hh, b_hh, h0)
-    return gru_sequence_reference(gi, w_hh, b_hh, h0)
+    unroll, reference core/qmix.py:241-253).  gi [B,T,J,3H] -> h_all [B,T,J,H]."""
+    if not gi.is_cuda:
+        return gru_sequence_reference(gi, w_hh, b_hh, h0)
+    return gru_sequence_multi([gi], [w_hh], [b_hh], [h0])[0]
+
+
+def gru_sequence_multi(gis, w_hhs, b_hhs, h0s=None):
+    """Up to two networks (eval + target) scanned in ONE launch on a HIP device; host tensors loop."""
+    n = len(gis)
+    h0s = h0s if h0s is not None else [None] * n
+    if not gis[0].is_cuda:
+        return [gru_sequence_reference(g, w, b, h) for g, w, b, h in zip(gis, w_hhs, b_hhs, h0s)]
+    lib = _native.load()
+    B, T, J, H3 = gis[0].shape
+    H = H3 // 3
+    if H not in (64, 128):
+        raise _native.NativeLibraryError(f"macjd_gru_sequence supports rnn_hidden_dim 64 or 128, got {H}")
+    outs = []
+    for start in range(0, n, 2):
+        io = _native.GruIO()
+        keep = []
+        cnt = min(2, n - start)
+        io.n_nets, io.B, io.T, io.J, io.H = cnt, B, T, J, H
+        for k in range(cnt):
+            g = gis[start + k].detach().float().contiguous()
+            w = w_hhs[start + k].detach().float().contiguous()
+            bb = b_hhs[start + k].detach().float().contiguous()
+            h0 = h0s[start + k]
+            if h0 is not None:
+                h0 = h0.detach().float().reshape(B * J, H).contiguous()
+            o = torch.empty((B, T, J, H), dtype=torch.float32, device=g.device)
+            keep += [g, w, bb, h0]
+            io.gi[k], io.w_hh[k], io.b_hh[k] = g.data_ptr(), w.data_ptr(), bb.data_ptr()
+            io.h0[k] = h0.data_ptr() if h0 is not None else None
+            io.h_out[k] = o.data_ptr()
+            outs.append(o)
+        with torch.cuda.device(gis[0].device):
+            _native.check(lib.macjd_gru_sequence(ctypes.byref(io), _stream(gis[0])), "macjd_gru_sequence")
+    return outs

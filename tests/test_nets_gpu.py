@@ -263,3 +263,28 @@ def test_reference_episode_end_to_end():
             np.testing.assert_allclose(got, ref, atol=TOL, rtol=0, err_msg=k)
     assert mac.action_selector.epsilon == pytest.approx(float(g["epsilon_after"]))
     assert runner.t_env == int(g["t_env_after"])
+
+
+@pytest.mark.parametrize("H", [64, 128])
+@pytest.mark.parametrize("B,T,J", [(1, 1, 1), (3, 7, 2), (32, 100, 3)])
+def test_gru_sequence_kernel(H, B, T, J):
+    """Fused GRU scan (one launch, eval + target weights together) == step-by-step torch.nn.GRUCell
+    arithmetic on the host (the oracle formulation), with and without an initial state."""
+    from macjd_amd import ops
+    rng = np.random.default_rng(H + T)
+    gis = [torch.tensor(rng.standard_normal((B, T, J, 3 * H)), dtype=torch.float32) for _ in range(2)]
+    ws = [torch.tensor(rng.standard_normal((3 * H, H)) / np.sqrt(H), dtype=torch.float32) for _ in range(2)]
+    bs = [torch.tensor(0.1 * rng.standard_normal(3 * H), dtype=torch.float32) for _ in range(2)]
+    h0 = torch.tensor(0.5 * rng.standard_normal((B * J, H)), dtype=torch.float32)
+    ref = [ops.gru_sequence_reference(gis[0], ws[0], bs[0]), ops.gru_sequence_reference(gis[1], ws[1], bs[1], h0)]
+    cell = torch.nn.GRUCell(H, H)   # cross-check the reference formulation against torch's own cell
+    with torch.no_grad():
+        cell.weight_hh.copy_(ws[0]); cell.bias_hh.copy_(bs[0])
+        cell.weight_ih.copy_(torch.eye(3 * H)[:, :H]); cell.bias_ih.zero_()
+    got = ops.gru_sequence_multi([g.to(DEV) for g in gis], [w.to(DEV) for w in ws], [b.to(DEV) for b in bs],
+                                 [None, h0.to(DEV)])
+    for g_, r_ in zip(got, ref):
+        assert g_.shape == (B, T, J, H)
+        np.testing.assert_allclose(g_.cpu().numpy(), r_.numpy(), atol=TOL, rtol=0)
+    single = ops.gru_sequence(gis[0].to(DEV), ws[0].to(DEV), bs[0].to(DEV))
+    assert torch.equal(single, got[0])
