@@ -55,29 +55,46 @@ def dist_setup(n_gpus):
 
 
 def cpu_baseline(sc, E, seed, budget_s=12.0):
-    """Times the CPU oracle (oracle/libmacjd_oracle.so, a port of the reference's step; kind="port")
-    on a bounded sample of the same workload: E envs x as many steps as fit in ~budget_s seconds."""
+    """Times the CPU oracle (oracle/libmacjd_oracle.so, a C port of the reference's env.step; kind="port")
+    on a bounded sample of the same workload.  Single thread: E envs per call (the reference itself is
+    single-threaded Python).  All cores: E envs PER THREAD per call (OpenMP over envs), so every thread
+    steps a full 4096-env batch.  Each leg runs ~budget_s/2 seconds."""
     import numpy as np
     sys.path.insert(0, os.path.join(REPO, "tests"))
     from _harness import OracleEnv, oracle_lib
     rng = np.random.default_rng(seed)
     J, R = sc.num_jammers, sc.num_radars
-    T = rng.integers(0, 2 * R + 1, size=(E, J)).astype(np.int32)
-    P = rng.random((E, J)).astype(np.float32)
     out = {}
-    cores_all = min(oracle_lib().macjd_oracle_max_threads(), os.cpu_count() or 1)
+    cores_all = max(1, min(oracle_lib().macjd_oracle_max_threads(), os.cpu_count() or 1))
     for label, nt in (("1", 1), ("all", cores_all)):
-        env = OracleEnv(sc, E, n_threads=nt)
+        n_env = E * nt
+        T = rng.integers(0, 2 * R + 1, size=(n_env, J)).astype(np.int32)
+        P = rng.random((n_env, J)).astype(np.float32)
+        env = OracleEnv(sc, n_env, n_threads=nt)
         env.step(T, P, seed=seed)  # warm
         n, t0 = 0, time.perf_counter()
         while True:
             env.step(T, P, seed=seed)
             n += 1
             dt = time.perf_counter() - t0
-            if dt > budget_s / 2 or n >= 2000:
+            if dt > budget_s / 2 or n >= 5000:
                 break
-        out[label] = (E * n / dt, nt, n)
+        out[label] = (n_env * n / dt, nt, n, n_env)
     return out
+
+
+def pmc_traffic(J, R, E):
+    """HBM bytes per env_step launch from the committed rocprofv3 PMC summary (profiles/), collected in
+    separate --pmc passes and corrected as MI355X_MICROARCH.md prescribes; None when no matching run."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_env_step_pmc.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("kernel", "").endswith(f"<{J},{R}>") and str(E) in d.get("runs", {}):
+            return d["runs"][str(E)]["traffic_bytes_per_launch"], os.path.basename(f)
+    return None, None
 
 
 def main():
@@ -157,7 +174,8 @@ def main():
     B_step = algorithmic_bytes_per_env_step(J, R, uniforms_supplied=False)
     achieved = E * B_step / (ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(J, R, E)[0],
+                "traffic_source": pmc_traffic(J, R, E)[1],
                 "kernel": f"env_step_kernel<{J},{R}>", "us_per_launch": round(ms * 1e3, 3),
                 "bytes_per_env_step": B_step, "envs_per_launch": E}
     sweep = None
@@ -191,10 +209,14 @@ def main():
             res["env_kernel_sweep"] = sweep
         if not args.no_cpu_baseline:
             cb = cpu_baseline(sc, E, seed=42)
-            res["cpu_baseline"] = {"value": round(cb["all"][0], 1), "unit": "env-steps/s", "cores": cb["all"][1],
-                                   "kind": "port",
-                                   "sample": f"C oracle of env.step, {E} envs x {cb['all'][2]} steps, OpenMP",
-                                   "single_core_value": round(cb["1"][0], 1)}
+            res["cpu_baseline"] = {
+                "value": round(cb["all"][0], 1), "unit": "env-steps/s", "cores": cb["all"][1], "kind": "port",
+                "sample": (f"C port (oracle) of reference env.step only, Philox uniforms: {cb['all'][3]} envs x "
+                           f"{cb['all'][2]} steps on {cb['all'][1]} OpenMP threads; single thread: {cb['1'][3]} envs x "
+                           f"{cb['1'][2]} steps"),
+                "single_core_value": round(cb["1"][0], 1),
+                "note": "covers env.step only; the Python reference measured in the build container (BASELINE.md): "
+                        "8725 env.step/s, 626 env-steps/s full rollout, ~1 env-step/s at its 1-train-per-step cadence"}
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
