@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--sweep", action="store_true", help="also print an E-sweep of the env kernel (stderr)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graphs", dest="no_graphs", action="store_true", help="eager launches (A/B against HIP graphs)")
     args = ap.parse_args()
 
     import torch
@@ -176,7 +177,7 @@ def main():
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(J, R, E)[0],
                 "traffic_source": pmc_traffic(J, R, E)[1],
-                "kernel": f"env_step_kernel<{J},{R}>", "us_per_launch": round(ms * 1e3, 3),
+                "kernel": (f"env_step_slots_kernel<{J},{R}>" if E < (1 << 17) else f"env_step_kernel<{J},{R}>"), "us_per_launch": round(ms * 1e3, 3),
                 "bytes_per_env_step": B_step, "envs_per_launch": E}
     sweep = None
     if args.sweep and rank == 0:
@@ -186,12 +187,18 @@ def main():
             e2 = BatchedElectromagneticEnvironment(scenario=sc, batch_envs=Es, device=dev, seed=1)
             Ts = torch.randint(0, 2 * R + 1, (J, Es), generator=g, device=dev, dtype=torch.int32).t()
             Ps = torch.rand((J, Es), generator=g, device=dev).t()
-            e2.time_step_kernel(Ts, Ps, iters=5)
-            m = e2.time_step_kernel(Ts, Ps, iters=50)
+            from macjd_amd import _native
+            ms_k = {}
+            for label, flag in (("auto", 0), ("slot", _native.STEP_SLOT_KERNEL), ("lane", _native.STEP_LANE_KERNEL)):
+                e2.kernel_flags = flag   # A/B of the two kernel variants on the same inputs, same process
+                e2.time_step_kernel(Ts, Ps, iters=5)
+                ms_k[label] = e2.time_step_kernel(Ts, Ps, iters=50)
+            m = ms_k["auto"]
             gbs = Es * B_step / (m * 1e-3) / 1e9
-            sweep.append({"E": Es, "us": round(m * 1e3, 2), "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)})
-            print(f"[sweep] E=2^{logE} {m*1e3:9.2f} us/launch  {gbs:8.1f} GB/s  frac {gbs/HBM_PEAK_GBS:.4f}",
-                  file=sys.stderr, flush=True)
+            sweep.append({"E": Es, "us": round(m * 1e3, 2), "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                          "us_slot_kernel": round(ms_k["slot"] * 1e3, 2), "us_lane_kernel": round(ms_k["lane"] * 1e3, 2)})
+            print(f"[sweep] E=2^{logE} {m*1e3:9.2f} us/launch  {gbs:8.1f} GB/s  frac {gbs/HBM_PEAK_GBS:.4f}"
+                  f"   (slot {ms_k['slot']*1e3:.2f} us, lane {ms_k['lane']*1e3:.2f} us)", file=sys.stderr, flush=True)
             e2.close()
 
     if rank == 0:

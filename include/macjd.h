@@ -47,6 +47,11 @@ extern "C" {
 /* macjd_step_io.flags bits */
 #define MACJD_STEP_ARITH_F64 1u /* P32 given, but do the power arithmetic in float64
                                    (NumPy-1.x value-based casting / python-float actions) */
+/* Kernel choice (results are bit-identical).  Default: the (env x slot) kernel for the templated scenario
+   sizes when n_envs < 2^17 (latency regime: shortest critical path), the one-lane-per-env kernel otherwise
+   (throughput regime: fewest instructions per env).  These two bits force one variant (A/B + tests). */
+#define MACJD_STEP_LANE_KERNEL 2u
+#define MACJD_STEP_SLOT_KERNEL 4u
 
 /*
  * Host-side description of one scenario: the static tables the scenario compiler derives from

@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(_PKG_DIR, LIB_NAME)
 
 ABI_VERSION = 1
 STEP_ARITH_F64 = 1
+STEP_LANE_KERNEL = 2
+STEP_SLOT_KERNEL = 4
 
 EXPORTS = [
     "macjd_abi_version", "macjd_last_error", "macjd_device_count",

@@ -47,8 +47,11 @@ def make_step(cli, sc, env, dev, rank, world, mode):
     runner = BatchedEpisodeRunner(env, mac, buf, args)
     T = args.episode_limit
     np.random.seed(1234 + rank)  # replay sampling stream (np.random.choice, like the reference)
+    use_graphs = not getattr(cli, "no_graphs", False)
     if mode == "train":
         runner.run(test_mode=False, sync_stats=False)  # untimed pre-fill of the replay buffer
+        if use_graphs:
+            learner.enable_graphs(buf, args.batch_size)
     stats_acc = {"loss": torch.zeros((), device=dev), "n": 0}
 
     def step_fn(i):
@@ -59,10 +62,13 @@ def make_step(cli, sc, env, dev, rank, world, mode):
         if t == T - 1:
             runner.end_episodes()
         if mode == "train":
-            st = learner.train(buf.sample(args.batch_size), None, sync_stats=False)
+            if use_graphs:
+                st = learner.train_from_buffer(sync_stats=False)
+            else:
+                st = learner.train(buf.sample(args.batch_size), None, sync_stats=False)
             stats_acc["loss"] += st["loss"]
             stats_acc["n"] += 1
 
     extra = {"hidden": cli.hidden, "train_batch_episodes": args.batch_size if mode == "train" else 0,
-             "train_calls_per_step": 1 if mode == "train" else 0, "replay_capacity_episodes": args.buffer_size}
+             "train_calls_per_step": 1 if mode == "train" else 0, "hip_graphs": bool(use_graphs and mode == "train"), "replay_capacity_episodes": args.buffer_size}
     return step_fn, extra

@@ -68,7 +68,7 @@ class RNNAgent(nn.Module):
         """Continuous parameter for EVERY discrete action, [N, A] in (0,1)  (networks.py:116-129)."""
         return self.actor(inputs)
 
-    def get_q_value_for_action(self, hidden_state, discrete_action_index, continuous_param):
+    def get_q_value_for_action(self, hidden_state, discrete_action_index, continuous_param, validate=True):
         """Q(h, T, P) for one (action, parameter) per row (networks.py:131-180).  Differentiable; this
         is the only path through which the learner's loss reaches the agent (core/qmix.py:161-184).
         Evaluated without building the one-hot / concatenated input: W1[:, H + T] is gathered."""
@@ -76,7 +76,9 @@ class RNNAgent(nn.Module):
         idx = discrete_action_index.long()
         if idx.dim() > 1 and idx.shape[1] == 1:
             idx = idx.squeeze(1)
-        if idx.numel() and (torch.any(idx < 0) or torch.any(idx >= self.n_actions)):  # networks.py:157-158
+        # the bounds check reads the device back (host sync); ``validate=False`` is for trusted indices
+        # inside a captured HIP graph (replay-buffer actions produced by select_actions)
+        if validate and idx.numel() and (torch.any(idx < 0) or torch.any(idx >= self.n_actions)):  # networks.py:157-158
             raise IndexError(f"Action index out of bounds: {idx}, n_actions: {self.n_actions}")
         if continuous_param.dim() == 1:
             continuous_param = continuous_param.unsqueeze(1)

@@ -64,7 +64,8 @@ class QMixLearner:
         self.agent_params = list(self.mac.parameters())
         self.qmix_params = list(self.eval_qmix_net.parameters())
         self.params = self.agent_params + self.qmix_params
-        self.optimizer = optim.Adam(params=self.params, lr=args.lr)
+        # capturable: the step counter lives on the device, so the update can sit inside a HIP graph
+        self.optimizer = optim.Adam(params=self.params, lr=args.lr, capturable=(self.device.type == "cuda"))
         self.last_target_update_step = 0
         self.train_step = 0
         self._flat_grad = None
@@ -94,11 +95,10 @@ class QMixLearner:
         self._flat_grad.div_(dist.get_world_size())
 
     # ------------------------------------------------------------------ the training step
-    def train(self, batch, train_info=None, sync_stats=True):
-        self.train_step += 1
+    def _forward_backward(self, batch, T, validate_actions=True):
+        """Loss + gradients for one batch of device/host arrays (no optimiser step, no host sync when
+        ``validate_actions`` is off).  Returns (loss, eval_q_mixer mean, targets mean) as 0-dim tensors."""
         dev = self.device
-        max_seq_len = int(batch["max_seq_len"])
-        T = max_seq_len
         states = _to(batch["state"], torch.float32, dev)[:, :T]
         obs = _to(batch["obs"], torch.float32, dev)[:, :T]
         actions_discrete = _to(batch["actions_discrete"], torch.long, dev)[:, :T]
@@ -130,35 +130,102 @@ class QMixLearner:
             q_taken = self.mac.agent.get_q_value_for_action(
                 hidden_states[:, :T - 1].reshape(n_eff, self.args.rnn_hidden_dim),
                 actions_discrete[:, :T - 1].reshape(n_eff, 1),
-                actions_continuous[:, :T - 1].reshape(n_eff, 1)).view(B, T - 1, self.n_agents)
+                actions_continuous[:, :T - 1].reshape(n_eff, 1), validate=validate_actions).view(B, T - 1, self.n_agents)
         eval_q_mixer = self.eval_qmix_net(q_taken, states[:, :-1])                  # qmix.py:187
 
         td_error = eval_q_mixer - targets.detach()                                   # qmix.py:190-194
         m = mask[:, :-1]
         loss = ((td_error * m.unsqueeze(-1)) ** 2).sum() / m.sum()
 
-        if self._flat_grad is None:
+        if self._flat_grad is None or self._flat_grad.device != self._trainable()[0].device:
             self._bind_flat_grads()
             for p in self.params:  # parameters the graph never reaches keep grad None, as in the reference
                 if not any(p is q for q in self._flat_params):
                     p.grad = None
         self._flat_grad.zero_()
         loss.backward()
-        self._allreduce_grads()
+        return loss.detach(), eval_q_mixer.detach().mean(), targets.mean()
+
+    def _clip_and_step(self):
         grad_norm = torch.nn.utils.clip_grad_norm_(self.params, self.args.grad_norm_clip)  # qmix.py:199
         self.optimizer.step()
+        return grad_norm.detach() if torch.is_tensor(grad_norm) else torch.as_tensor(grad_norm)
 
+    def _after_step(self):
         if (self.train_step - self.last_target_update_step) >= self.args.target_update_interval:  # qmix.py:203-205
             self._update_targets()
             self.last_target_update_step = self.train_step
 
-        stats = {"loss": loss.detach(), "grad_norm": grad_norm.detach() if torch.is_tensor(grad_norm) else grad_norm,
-                 "eval_qtot_avg": eval_q_mixer.detach().mean(), "target_qtot_avg": targets.mean()}
+    def _pack_stats(self, loss, grad_norm, ev, tg, sync_stats):
+        stats = {"loss": loss, "grad_norm": grad_norm, "eval_qtot_avg": ev, "target_qtot_avg": tg}
         if sync_stats:  # the reference returns Python floats (4 x .item(), qmix.py:209-214)
-            stacked = torch.stack([torch.as_tensor(v, device=dev, dtype=torch.float32).reshape(()) for v in stats.values()])
-            vals = stacked.tolist()  # one host sync instead of four
-            stats = dict(zip(stats.keys(), vals))
+            stacked = torch.stack([torch.as_tensor(v, device=self.device, dtype=torch.float32).reshape(())
+                                   for v in stats.values()])
+            stats = dict(zip(stats.keys(), stacked.tolist()))  # one host sync instead of four
         return stats
+
+    def train(self, batch, train_info=None, sync_stats=True):
+        """One QMix update on a batch dict (reference signature, core/qmix.py:76-215)."""
+        self.train_step += 1
+        loss, ev, tg = self._forward_backward(batch, int(batch["max_seq_len"]))
+        self._allreduce_grads()
+        grad_norm = self._clip_and_step()
+        self._after_step()
+        return self._pack_stats(loss, grad_norm, ev, tg, sync_stats)
+
+    # ------------------------------------------------------------------ HIP-graph path
+    def enable_graphs(self, buffer, batch_size, warmup_iters=3):
+        """Capture the update as two HIP graphs around the (eager) gradient all-reduce:
+          graph A  gather the sampled episodes from the device replay (static index tensor) + both
+                   unrolls + mixers + loss + backward                      (~300 launches -> 1 graph launch)
+          graph B  gradient clipping + Adam + the four logged scalars
+        Valid while every stored episode has the full ``episode_limit`` length (true for this env: episodes
+        only end at the limit, environment.py:460); ``train_from_buffer`` falls back to the eager path
+        otherwise.  The replay tensors, parameters, gradients and optimiser state keep their addresses, so
+        target syncs (in-place ``load_state_dict``) and new episodes are seen by the replayed graphs."""
+        if self.device.type != "cuda":
+            raise RuntimeError("enable_graphs needs the learner on a HIP device")
+        self._g_buffer, self._g_B, self._g_T = buffer, int(batch_size), int(buffer.episode_limit)
+        self._g_idx = torch.zeros(self._g_B, dtype=torch.int64, device=self.device)
+        if buffer.current_size < 1:
+            raise RuntimeError("enable_graphs: the replay buffer is empty")
+
+        def body_a():
+            b = {k: v.index_select(0, self._g_idx) for k, v in buffer.buffers.items()}
+            return self._forward_backward(b, self._g_T, validate_actions=False)
+
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):  # eager warm-up on a side stream (initialises the optimiser state)
+            for _ in range(warmup_iters):
+                body_a()
+                self._clip_and_step()
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        self._graph_a, self._graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph_a):
+            self._g_out_a = body_a()
+        with torch.cuda.graph(self._graph_b, pool=self._graph_a.pool()):
+            self._g_out_b = self._clip_and_step()
+        self._graphs_ready = True
+
+    def train_from_buffer(self, indices=None, sync_stats=True):
+        """Sample ``batch_size`` whole episodes (np.random.choice like the reference's buffer) and update."""
+        buf = self._g_buffer if getattr(self, "_graphs_ready", False) else None
+        if buf is None:
+            raise RuntimeError("call enable_graphs(buffer, batch_size) first")
+        if indices is None:
+            indices = np.random.choice(buf.current_size, self._g_B, replace=False)
+        indices = np.asarray(indices, dtype=np.int64)
+        if len(indices) != self._g_B or int(buf.episode_lengths[indices].min()) != self._g_T:
+            return self.train(buf.sample(len(indices), indices=indices), None, sync_stats=sync_stats)
+        self.train_step += 1
+        self._g_idx.copy_(torch.from_numpy(indices))
+        self._graph_a.replay()
+        self._allreduce_grads()
+        self._graph_b.replay()
+        self._after_step()
+        loss, ev, tg = self._g_out_a
+        return self._pack_stats(loss, self._g_out_b, ev, tg, sync_stats)
 
     def _all_action_q_multi(self, macs, obs):
         """Q(s_t, a, P_a(s_t)) for every discrete action, [B, T, J, A] per controller; replaces the

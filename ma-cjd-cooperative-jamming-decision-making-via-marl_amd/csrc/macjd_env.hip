@@ -229,6 +229,209 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// env_step_slots_kernel: one lane = one (env, slot) pair, slot = a jammer or a radar.
+//
+// Workgroup = 64 consecutive envs x (NJW jammer waves + NRW radar waves).  Lane l of every wave works on
+// env 64*blockIdx.x + l, so agent-major / radar-major tensors are read and written as whole 256-B rows.
+//   phase 1  jammer waves: decode, power, r_p term, received power          -> LDS (prj, meta, r_p term)
+//   phase 2  jammer waves: deception false-target Pd + Monte-Carlo hit      -> LDS (1 - min(pd_f, .999999))
+//            radar waves (concurrently): suppression sum in jammer order, SNR, Pd, detection draw, FSM,
+//            r_d / r_j(suppression) terms; pd / snr / track outputs           -> LDS (r_d, r_j terms)
+//   phase 3  radar waves: per-radar deception product in jammer order        -> LDS
+//   phase 4  wave 0: the three ordered sums (radar / jammer index order, as the reference), outputs.
+// The arithmetic, operation order and RNG slots are identical to env_step_kernel (and the reference);
+// only the placement on lanes changes: the per-env critical path is two Pd evaluations instead of J + R,
+// there is no per-lane J x R select chain and no divergent deception branch inside a radar/jammer lane.
+// Tables indexed by the lane's chosen target radar (<= 128-B rows of a <= 11.5 KB table shared by the whole
+// grid) are gathered straight from L1/L2; radar-wave constants are wave-uniform scalar loads.
+template <int J, int R, int NJW, int NRW>
+__global__ void __launch_bounds__(64 * (NJW + NRW)) env_step_slots_kernel(const DevTables* __restrict__ tb,
+                                                                          const macjd_step_io io) {
+    constexpr int JPW = (J + NJW - 1) / NJW;
+    constexpr int RPW = (R + NRW - 1) / NRW;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t e_raw = (int64_t)blockIdx.x * 64 + lane;
+    const bool active = e_raw < io.n_envs;
+    const int64_t e = active ? e_raw : io.n_envs - 1;  // clamp: inactive lanes compute on a valid env, store nothing
+
+    __shared__ double s_prj[J][64];
+    __shared__ double s_rpterm[J][64];
+    __shared__ double s_hitfac[J][64];
+    __shared__ int s_meta[J][64];  // bits 0..7 target radar, bit 8 valid suppression, bit 9 valid deception
+    __shared__ double s_rd[R][64], s_rjs[R][64], s_rjd[R][64];
+
+    const double pdA = tb->pd_A, pdc1 = tb->pd_c1, pdden = tb->pd_denB;
+    const bool arith32 = (io.P32 != nullptr) && !(io.flags & MACJD_STEP_ARITH_F64);
+    const int32_t step_before = io.step[e];
+    const bool jam_wave = wave < NJW;
+
+    // ---------------- phase 1: jammer lanes, environment.py:248-302 ----------------
+    double my_prj[JPW];
+    int my_meta[JPW];
+    if (jam_wave) {
+#pragma unroll
+        for (int jj = 0; jj < JPW; ++jj) {
+            const int j = wave + jj * NJW;  // wave-uniform
+            my_prj[jj] = 0.0;
+            my_meta[jj] = 0;
+            if (j < J) {
+                const int32_t T = io.T[e * io.T_se + (int64_t)j * io.T_sx];
+                const bool is_jamming = (T >= 1) && (T <= 2 * R);
+                const int target = is_jamming ? ((T + 1) / 2 - 1) : 0;
+                const int jtype = T % 2;
+                const double pmin = tb->pmin[j], pmax = tb->pmax[j];
+                const double power_range = pmax - pmin;
+                double actual_d, norm;
+                float actual_f = 0.0f;
+                if (arith32) {
+                    float Pc = io.P32[e * io.P_se + (int64_t)j * io.P_sx];
+                    Pc = Pc < 0.0f ? 0.0f : (Pc > 1.0f ? 1.0f : Pc);
+                    actual_f = (float)pmin + Pc * (float)power_range;
+                    actual_d = (double)actual_f;
+                    norm = (power_range > 1e-6) ? (double)((actual_f - (float)pmin) / (float)power_range) : 0.0;
+                } else {
+                    double Pc = io.P64 ? io.P64[e * io.P_se + (int64_t)j * io.P_sx]
+                                       : (double)io.P32[e * io.P_se + (int64_t)j * io.P_sx];
+                    Pc = Pc < 0.0 ? 0.0 : (Pc > 1.0 ? 1.0 : Pc);
+                    actual_d = pmin + Pc * power_range;
+                    norm = (power_range > 1e-6) ? (actual_d - pmin) / power_range : 0.0;
+                }
+                const double denom = tb->denom[j * R + target];
+                const bool recorded = is_jamming && (actual_d > 0.0) && (denom >= 0.0);
+                double prj = 0.0;
+                if (recorded && denom > 1e-18) {
+                    const double grj = tb->gr[target];
+                    if (arith32) {
+                        const float num = (actual_f * (float)tb->gj[j]) * (float)grj;
+                        prj = (tb->flags[j * R + target] & MACJD_JR_WEAK_DENOM) ? (double)(num / (float)denom)
+                                                                               : (double)num / denom;
+                    } else {
+                        prj = (actual_d * tb->gj[j] * grj) / denom;
+                    }
+                    prj = (prj > 0.0) ? prj : 0.0;
+                }
+                const int meta = target | ((recorded && jtype == 1) ? 0x100 : 0) | ((recorded && jtype == 0) ? 0x200 : 0);
+                my_prj[jj] = prj;
+                my_meta[jj] = meta;
+                s_prj[j][lane] = prj;
+                s_meta[j][lane] = meta;
+                s_rpterm[j][lane] = tb->rp_max + (tb->rp_min - tb->rp_max) * norm;  // environment.py:377
+                if (io.prj64 && active) io.prj64[e * J + j] = recorded ? prj : -1.0;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase 2 ----------------
+    if (jam_wave) {
+        // deception: false-target detection, environment.py:410-434
+#pragma unroll
+        for (int jj = 0; jj < JPW; ++jj) {
+            const int j = wave + jj * NJW;
+            if (j < J) {
+                double hitfac = -1.0;
+                if (my_meta[jj] & 0x200) {
+                    int k = 0;  // valid deception actions of lower-numbered jammers -> RNG slot R + k
+                    for (int j2 = 0; j2 < j; ++j2) k += (s_meta[j2][lane] >> 9) & 1;
+                    const int target = my_meta[jj] & 0xff;
+                    const double Pn_t = tb->Pn[target];
+                    double snr_f = (Pn_t > 1e-18) ? (tb->D[target] * my_prj[jj]) / Pn_t : 0.0;
+                    snr_f = (snr_f > 0.0) ? snr_f : 0.0;
+                    const double pd_f = det_prob(snr_f, pdA, pdc1, pdden);
+                    const double u = draw_uniform(io, e, R + k, (uint32_t)step_before);
+                    if (u <= pd_f) hitfac = 1.0 - (pd_f < 0.999999 ? pd_f : 0.999999);
+                }
+                s_hitfac[j][lane] = hitfac;
+            }
+        }
+    } else {
+        // radars: detections, FSM, r_d, r_j(suppression); environment.py:316-398
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = (wave - NJW) + rr * NRW;  // wave-uniform
+            if (r < R) {
+                double supp = 0.0;
+                bool targeted = false;
+#pragma unroll
+                for (int j = 0; j < J; ++j) {  // jammer order, environment.py:299
+                    const int meta = s_meta[j][lane];
+                    const bool hit = (meta & 0x100) && ((meta & 0xff) == r);
+                    supp += hit ? s_prj[j][lane] : 0.0;
+                    targeted |= hit;
+                }
+                const double Pn = tb->Pn[r];
+                const double den = tb->D[r] * supp + Pn;
+                const double snr_with = (den > 1e-18) ? tb->GaPs[r] / den : 0.0;
+                const double pd = det_prob(snr_with, pdA, pdc1, pdden);
+                const double u = draw_uniform(io, e, r, (uint32_t)step_before);
+                const bool tracking = (u <= pd);  // next FSM state == detected (radar.py:102-117)
+                const double red = tb->pd_no[r] - pd;
+                s_rd[r][lane] = tracking ? tb->rd_pen[r] : 0.0;
+                s_rjs[r][lane] = (targeted && red > 0.0) ? red : 0.0;
+                if (active) {
+                    const double snr_rep = (snr_with > 0.0) ? snr_with : 0.0;
+                    io.track[e * io.k_se + (int64_t)r * io.k_sx] = tracking ? 1 : 0;
+                    if (io.pd) io.pd[e * io.pd_se + (int64_t)r * io.pd_sx] = (float)pd;
+                    if (io.snr_with) io.snr_with[e * io.sw_se + (int64_t)r * io.sw_sx] = (float)snr_rep;
+                    if (io.pd64) io.pd64[e * R + r] = pd;
+                    if (io.snr64) io.snr64[e * R + r] = snr_rep;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase 3: per-radar deception product, environment.py:437-451 ----------------
+    if (!jam_wave) {
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = (wave - NJW) + rr * NRW;
+            if (r < R) {
+                double prod = 1.0;
+                bool any = false;
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const int meta = s_meta[j][lane];
+                    const double hf = s_hitfac[j][lane];
+                    const bool hit = (meta & 0x200) && ((meta & 0xff) == r) && (hf >= 0.0);
+                    prod = hit ? prod * hf : prod;
+                    any |= hit;
+                }
+                s_rjd[r][lane] = any ? (1.0 - prod) : 0.0;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase 4: ordered sums + per-env outputs, environment.py:353-460 ----------------
+    if (wave == 0 && active) {
+        double r_d = 0.0, r_p = 0.0, r_j = 0.0, r_j_dec = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { r_d += s_rd[r][lane]; r_j += s_rjs[r][lane]; r_j_dec += s_rjd[r][lane]; }
+#pragma unroll
+        for (int j = 0; j < J; ++j) r_p += s_rpterm[j][lane];
+        r_j += r_j_dec;
+        const double reward = r_d + r_p + r_j;
+        const int32_t step_count = step_before + 1;
+        io.step[e] = step_count;
+        if (io.terminated) io.terminated[e] = (step_count >= tb->episode_limit) ? 1 : 0;
+        if (io.reward) io.reward[e] = (float)reward;
+        if (io.r_dpj) {
+            io.r_dpj[e * 3 + 0] = (float)r_d;
+            io.r_dpj[e * 3 + 1] = (float)r_p;
+            io.r_dpj[e * 3 + 2] = (float)r_j;
+        }
+        if (io.out64) {
+            io.out64[e * 4 + 0] = reward;
+            io.out64[e * 4 + 1] = r_d;
+            io.out64[e * 4 + 2] = r_p;
+            io.out64[e * 4 + 3] = r_j;
+        }
+    }
+}
+
 __global__ void env_reset_kernel(int64_t n_envs, int R, uint8_t* track, int64_t k_se, int64_t k_sx, int32_t* step,
                                  const uint8_t* mask) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_envs;
@@ -339,21 +542,39 @@ static int validate_io(const macjd_scenario* s, const macjd_step_io* io) {
 
 static int launch_step(const macjd_scenario* s, const macjd_step_io* io, hipStream_t stream) {
     const int64_t E = io->n_envs;
-    // small batches: one wave per workgroup spreads the envs over more CUs (latency-bound regime);
-    // large batches: 256-lane workgroups, grid-stride, tables staged once per workgroup.
-    const int block = (E >= (1 << 16)) ? 256 : 64;
-    int64_t grid = (E + block - 1) / block;
-    const int64_t cap = (block == 256) ? 256 * 8 : 256 * 16;
-    if (grid > cap) grid = cap;
-    const dim3 g((unsigned)grid), b(block);
     const int J = s->host.J, R = s->host.R;
+    const bool has_slot_kernel = (J == 3 && R == 4) || (J == 6 && R == 8) || (J == 12 && R == 16) || (J == 2 && R == 2);
+    // measured crossover on MI355X (3j/4r, round 1): slot kernel 4.4 / 8.0 / 24.9 us vs lane kernel 9.2 / 10.1 /
+    // 21.8 us at E = 2^12 / 2^16 / 2^18
+    bool slot_kernel = has_slot_kernel && E < (1 << 17);
+    if (io->flags & MACJD_STEP_LANE_KERNEL) slot_kernel = false;
+    if ((io->flags & MACJD_STEP_SLOT_KERNEL) && has_slot_kernel) slot_kernel = true;
+    if (slot_kernel) {  // one workgroup per 64 envs
+        const dim3 g((unsigned)((E + 63) / 64));
+#define MACJD_SLOTS(JT, RT, NJW, NRW) \
+    hipLaunchKernelGGL((macjd::env_step_slots_kernel<JT, RT, NJW, NRW>), g, dim3(64 * (NJW + NRW)), 0, stream, s->dev, *io)
+        if (J == 3) MACJD_SLOTS(3, 4, 3, 4);
+        else if (J == 6) MACJD_SLOTS(6, 8, 6, 8);
+        else if (J == 12) MACJD_SLOTS(12, 16, 4, 8);
+        else MACJD_SLOTS(2, 2, 2, 2);
+#undef MACJD_SLOTS
+    } else {
+        // generic sizes (and the A/B hook): one lane per env
+        // small batches: one wave per workgroup spreads the envs over more CUs (latency-bound regime);
+        // large batches: 256-lane workgroups, grid-stride, tables staged once per workgroup.
+        const int block = (E >= (1 << 16)) ? 256 : 64;
+        int64_t grid = (E + block - 1) / block;
+        const int64_t cap = (block == 256) ? 256 * 8 : 256 * 16;
+        if (grid > cap) grid = cap;
+        const dim3 g((unsigned)grid), b(block);
 #define MACJD_LAUNCH(JT, RT) hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT>), g, b, 0, stream, s->dev, *io)
-    if (J == 3 && R == 4) MACJD_LAUNCH(3, 4);
-    else if (J == 6 && R == 8) MACJD_LAUNCH(6, 8);
-    else if (J == 12 && R == 16) MACJD_LAUNCH(12, 16);
-    else if (J == 2 && R == 2) MACJD_LAUNCH(2, 2);
-    else MACJD_LAUNCH(0, 0);
+        if (J == 3 && R == 4) MACJD_LAUNCH(3, 4);
+        else if (J == 6 && R == 8) MACJD_LAUNCH(6, 8);
+        else if (J == 12 && R == 16) MACJD_LAUNCH(12, 16);
+        else if (J == 2 && R == 2) MACJD_LAUNCH(2, 2);
+        else MACJD_LAUNCH(0, 0);
 #undef MACJD_LAUNCH
+    }
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_env_step launch: %s", hipGetErrorString(err));
     return MACJD_OK;

@@ -96,6 +96,7 @@ class BatchedElectromagneticEnvironment:
         self._avail = torch.ones((1, 1, sc.n_actions), dtype=torch.int32, device=dev)
         self._snr_no = torch.from_numpy(sc.tables["radar_snr_no"]).to(dev)
         self._io = _native.StepIO()
+        self.kernel_flags = 0  # A/B hook: _native.STEP_LANE_KERNEL / STEP_SLOT_KERNEL force one kernel variant
         if verbose:
             print(f"Batched environment: {E} envs x {J} jammers / {R} radars on {dev} (from {sc.source})")
 
@@ -157,7 +158,7 @@ class BatchedElectromagneticEnvironment:
             raise ValueError("actions must live on the environment's device")
         io = self._io
         io.n_envs, io.env_offset, io.seed = E, self.env_offset, self.seed
-        io.flags = _native.STEP_ARITH_F64 if arith_f64 else 0
+        io.flags = (_native.STEP_ARITH_F64 if arith_f64 else 0) | self.kernel_flags
         io.T, io.T_se, io.T_sx = T.data_ptr(), T.stride(0), T.stride(1)
         if P.dtype == torch.float32:
             io.P32, io.P64 = P.data_ptr(), None

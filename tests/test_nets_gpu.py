@@ -288,3 +288,44 @@ def test_gru_sequence_kernel(H, B, T, J):
         np.testing.assert_allclose(g_.cpu().numpy(), r_.numpy(), atol=TOL, rtol=0)
     single = ops.gru_sequence(gis[0].to(DEV), ws[0].to(DEV), bs[0].to(DEV))
     assert torch.equal(single, got[0])
+
+
+def test_graphed_train_equals_eager_train():
+    """HIP-graph replay of the learner step == the eager step: same sampled episodes -> same losses and
+    the same weights after several updates incl. a target sync."""
+    from macjd_amd.core.mac import BasicMAC
+    from macjd_amd.core.qmix import QMixLearner
+    from macjd_amd.utils.replay_buffer import EpisodeReplayBuffer
+    from tests_golden_helpers import synthetic_batch
+    g, d = load("3j4r_h64")
+    T, N, B = 12, 40, 8
+    def build():
+        args = _gpu_args(d, episode_limit=T, buffer_size=N, batch_size=B, target_update_interval=3)
+        with quiet():
+            mac = BasicMAC(d["S"], args)
+            mac.load_state(sd_from(g, "g5_agent0."))
+            learner = QMixLearner(mac, args)
+            buf = EpisodeReplayBuffer(args)
+        learner.eval_qmix_net.load_state_dict(sd_from(g, "g5_mixer0."))
+        learner._update_targets()
+        full = synthetic_batch(np.random.default_rng(9), args, N, T)
+        for k, v in buf.buffers.items():
+            v.copy_(torch.as_tensor(full[k]).to(v.dtype))
+        buf.current_size, buf.current_index = N, 0
+        buf.episode_lengths[:] = T
+        return mac, learner, buf
+    mac_e, eager, buf_e = build()
+    mac_g, graphed, buf_g = build()
+    graphed.enable_graphs(buf_g, B, warmup_iters=0)   # no warm-up updates so both start from the same weights
+    rng = np.random.default_rng(1)
+    for step in range(7):
+        idx = rng.choice(N, B, replace=False)
+        se = eager.train(buf_e.sample(B, indices=idx), {})
+        sg = graphed.train_from_buffer(indices=idx)
+        for k in se:
+            assert sg[k] == pytest.approx(se[k], rel=1e-4, abs=1e-6), (step, k)
+    assert graphed.train_step == eager.train_step == 7 and graphed.last_target_update_step == 6
+    for (k, a), b in zip(mac_e.agent.state_dict().items(), mac_g.agent.state_dict().values()):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-6, rtol=0, err_msg=k)
+    for (k, a), b in zip(eager.target_qmix_net.state_dict().items(), graphed.target_qmix_net.state_dict().values()):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-6, rtol=0, err_msg=k)
