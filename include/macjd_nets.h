@@ -44,6 +44,10 @@ typedef struct macjd_qhead_io {
     int64_t av_se, av_sj, av_sa;           /* avail element strides over (env, agent, action) */
     float epsilon;      float reserved2;   /* exploration probability (action_selectors.py:30-32) */
     uint64_t seed, counter;                /* Philox key / call counter for the exploration draws */
+    /* optional device-side sources, for launches replayed from a captured HIP graph (kernel arguments
+       are frozen at capture): *eps_dev replaces epsilon, *counter_dev is ADDED to counter */
+    const float* eps_dev;
+    const uint64_t* counter_dev;
     int32_t* T_out32;                      /* optional chosen action, int32 */
     int64_t* T_out64;                      /* optional chosen action, int64 */
     int64_t t32_se, t32_sj, t64_se, t64_sj;/* element strides over (env, agent) */

@@ -62,6 +62,7 @@ class QheadIO(ctypes.Structure):
         ("av_se", ctypes.c_int64), ("av_sj", ctypes.c_int64), ("av_sa", ctypes.c_int64),
         ("epsilon", ctypes.c_float), ("reserved2", ctypes.c_float),
         ("seed", ctypes.c_uint64), ("counter", ctypes.c_uint64),
+        ("eps_dev", ctypes.c_void_p), ("counter_dev", ctypes.c_void_p),
         ("T_out32", ctypes.c_void_p), ("T_out64", ctypes.c_void_p),
         ("t32_se", ctypes.c_int64), ("t32_sj", ctypes.c_int64), ("t64_se", ctypes.c_int64), ("t64_sj", ctypes.c_int64),
         ("P_out", ctypes.c_void_p), ("po_se", ctypes.c_int64), ("po_sj", ctypes.c_int64),

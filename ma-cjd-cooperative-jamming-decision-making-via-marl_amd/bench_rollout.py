@@ -52,23 +52,32 @@ def make_step(cli, sc, env, dev, rank, world, mode):
         runner.run(test_mode=False, sync_stats=False)  # untimed pre-fill of the replay buffer
         if use_graphs:
             learner.enable_graphs(buf, args.batch_size)
-    stats_acc = {"loss": torch.zeros((), device=dev), "n": 0}
+    if use_graphs:
+        runner.enable_graph()
+    total = cli.warmup + cli.steps
+    state = {"graphed_episode": False}
 
     def step_fn(i):
         t = i % T
         if t == 0:
-            runner.begin_episodes()
-        runner.step(t)
+            # a whole episode batch (reset + T batched steps) is ONE graph launch when it fits in the
+            # remaining step budget; otherwise (trailing partial episode) the steps are launched one by one
+            state["graphed_episode"] = use_graphs and (i + T <= total)
+            if state["graphed_episode"]:
+                runner.rollout_graphed()
+            else:
+                runner.begin_episodes()
+        if not state["graphed_episode"]:
+            runner.step(t)
         if t == T - 1:
             runner.end_episodes()
         if mode == "train":
             if use_graphs:
-                st = learner.train_from_buffer(sync_stats=False)
+                learner.train_from_buffer(sync_stats=False)
             else:
-                st = learner.train(buf.sample(args.batch_size), None, sync_stats=False)
-            stats_acc["loss"] += st["loss"]
-            stats_acc["n"] += 1
+                learner.train(buf.sample(args.batch_size), None, sync_stats=False)
 
     extra = {"hidden": cli.hidden, "train_batch_episodes": args.batch_size if mode == "train" else 0,
-             "train_calls_per_step": 1 if mode == "train" else 0, "hip_graphs": bool(use_graphs and mode == "train"), "replay_capacity_episodes": args.buffer_size}
+             "train_calls_per_step": 1 if mode == "train" else 0, "hip_graphs": bool(use_graphs),
+             "replay_capacity_episodes": args.buffer_size}
     return step_fn, extra

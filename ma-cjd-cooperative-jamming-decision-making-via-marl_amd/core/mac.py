@@ -36,6 +36,9 @@ class BasicMAC:
         self.last_actions_P = None    # float32 [E, J, 1] view of agent-major storage (HIP path)
         self.last_q_values = None     # [E, J, A] unmasked Q-values of the last call when keep_q_values is set
         self.keep_q_values = False
+        # (eps float32[1], counter int64[1]) device tensors; when set, the fused select kernel reads the
+        # exploration probability / Philox call counter from them (HIP-graph replay, see BatchedEpisodeRunner)
+        self.device_schedule = None
 
     def select_actions(self, obs_batch, avail_actions_batch, t_env, test_mode=False):
         device = next(self.agent.parameters()).device
@@ -57,10 +60,13 @@ class BasicMAC:
             eps = self.action_selector.anneal(t_env, test_mode)
             if base.is_cuda:
                 self._select_calls += 1
+                eps_dev, ctr_dev, counter = None, None, self._select_calls
+                if self.device_schedule is not None:
+                    eps_dev, ctr_dev, counter = self.device_schedule
                 T64, P_sel, T32, Q = ops.qhead_select(
                     base, params_all, l1.weight, l2.weight, l2.bias, H, A, self.n_agents, avail_actions_batch,
-                    epsilon=eps, greedy_only=test_mode, seed=self.select_seed, counter=self._select_calls,
-                    want_q=self.keep_q_values)
+                    epsilon=eps, greedy_only=test_mode, seed=self.select_seed, counter=counter,
+                    want_q=self.keep_q_values, eps_dev=eps_dev, counter_dev=ctr_dev)
                 self.last_actions_T32, self.last_actions_P = T32, P_sel
                 self.last_q_values = Q.view(batch_size, self.n_agents, A) if Q is not None else None
                 return T64, P_sel

@@ -194,13 +194,27 @@ class QMixLearner:
             b = {k: v.index_select(0, self._g_idx) for k, v in buffer.buffers.items()}
             return self._forward_backward(b, self._g_T, validate_actions=False)
 
+        # Eager warm-up on a side stream: allocates the optimiser state BEFORE capture (state created during
+        # capture would be re-initialised by every replay) and lets the libraries pick their kernels.  The
+        # warm-up updates are then undone in place, so enabling graphs does not change the training state.
+        snap_p = [p.detach().clone() for p in self.params]
+        snap_o = {id(p): {k: v.clone() for k, v in st.items() if torch.is_tensor(v)}
+                  for p, st in self.optimizer.state.items()}
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(s):  # eager warm-up on a side stream (initialises the optimiser state)
-            for _ in range(warmup_iters):
+        with torch.cuda.stream(s):
+            for _ in range(max(1, warmup_iters)):
                 body_a()
                 self._clip_and_step()
         torch.cuda.current_stream(self.device).wait_stream(s)
+        with torch.no_grad():
+            for p, sp in zip(self.params, snap_p):
+                p.copy_(sp)
+            for p, st in self.optimizer.state.items():
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        old = snap_o.get(id(p), {}).get(k)
+                        v.copy_(old) if old is not None else v.zero_()
         self._graph_a, self._graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph_a):
             self._g_out_a = body_a()

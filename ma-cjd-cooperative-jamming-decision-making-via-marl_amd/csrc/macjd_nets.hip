@@ -100,11 +100,13 @@ __global__ void __launch_bounds__(256) qhead_select_kernel(const macjd_qhead_io 
         if (q > bestq) { bestq = q; best = a; }
     }
     int chosen = best;
-    if (!io.greedy_only && io.epsilon > 0.0f) {
-        const Philox4 r = philox4x32_10((uint32_t)n, (uint32_t)((uint64_t)n >> 32), (uint32_t)io.counter,
-                                        (uint32_t)(io.counter >> 32), (uint32_t)io.seed, (uint32_t)(io.seed >> 32));
+    const float epsilon = io.eps_dev ? io.eps_dev[0] : io.epsilon;
+    if (!io.greedy_only && epsilon > 0.0f) {
+        const uint64_t counter = io.counter + (io.counter_dev ? io.counter_dev[0] : 0ull);
+        const Philox4 r = philox4x32_10((uint32_t)n, (uint32_t)((uint64_t)n >> 32), (uint32_t)counter,
+                                        (uint32_t)(counter >> 32), (uint32_t)io.seed, (uint32_t)(io.seed >> 32));
         const float u_pick = (float)(r.v[0] >> 8) * (1.0f / 16777216.0f);
-        if (u_pick < io.epsilon) {
+        if (u_pick < epsilon) {
             // uniform over the available actions (torch.multinomial over the mask in the reference);
             // with no action available the reference falls back to uniform over all of them
             const int pool = n_avail > 0 ? n_avail : A;

@@ -60,7 +60,8 @@ def qhead_all_actions(base, P_all, W1, w2, b2, H: int, A: int) -> torch.Tensor:
 
 
 def qhead_select(base, P_all, W1, w2, b2, H: int, A: int, n_agents: int, avail: Optional[torch.Tensor],
-                 epsilon: float, greedy_only: bool, seed: int, counter: int, want_q: bool = False
+                 epsilon: float, greedy_only: bool, seed: int, counter: int, want_q: bool = False,
+                 eps_dev: Optional[torch.Tensor] = None, counter_dev: Optional[torch.Tensor] = None
                  ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
     """Fused all-action Q + mask + epsilon-greedy + gather on a HIP device.
 
@@ -93,6 +94,12 @@ def qhead_select(base, P_all, W1, w2, b2, H: int, A: int, n_agents: int, avail: 
         io.avail, io.avail_elem_size = avail.data_ptr(), avail.element_size()
         io.av_se, io.av_sj, io.av_sa = avail.stride(0), avail.stride(1), avail.stride(2)
     io.epsilon, io.seed, io.counter = float(epsilon), int(seed) & (2 ** 64 - 1), int(counter) & (2 ** 64 - 1)
+    if eps_dev is not None:      # float32 [1] on the device: exploration probability read at run time
+        assert eps_dev.dtype == torch.float32 and eps_dev.device == dev
+        io.eps_dev = eps_dev.data_ptr()
+    if counter_dev is not None:  # int64 [1] on the device: added to ``counter`` at run time
+        assert counter_dev.dtype == torch.int64 and counter_dev.device == dev
+        io.counter_dev = counter_dev.data_ptr()
     io.T_out32, io.t32_se, io.t32_sj = T32.data_ptr(), 1, E
     io.T_out64, io.t64_se, io.t64_sj = T64.data_ptr(), n_agents, 1
     io.P_out, io.po_se, io.po_sj = P_am.data_ptr(), 1, E

@@ -180,6 +180,8 @@ class BatchedEpisodeRunner:
         self._static = bool(getattr(env, "observation_is_static", False))
         self._static_filled = False
         self._rdpj_sum = z((E, 3), torch.float32)
+        self._ep = -1
+        self._graph = None
 
     def _fill_static(self):
         T = self.episode_limit
@@ -190,6 +192,7 @@ class BatchedEpisodeRunner:
 
     def begin_episodes(self):
         """Reset the E envs and the recurrent state; (re)fill static rows once."""
+        self._ep += 1  # episode-batch index; with the step index it forms the select kernel's Philox counter
         self.mac.init_hidden(batch_size=self.batch_envs)
         self.env.reset()
         if self._static and not self._static_filled:
@@ -206,6 +209,9 @@ class BatchedEpisodeRunner:
             st["state"][t].copy_(env.get_state())
             st["obs"][t].copy_(self._obs)
             st["avail_actions"][t].copy_(self._avail)
+        # exploration draws are keyed by (seed; row, counter) with counter = ep * (T + 1) + t + 1, the same in
+        # eager and graph-replayed rollouts (select_actions pre-increments its call counter)
+        mac._select_calls = self._ep * (self.episode_limit + 1) + t
         T64, P_sel = mac.select_actions(self._obs, self._avail, self.t_env, test_mode=test_mode)
         st["hidden_state"][t].copy_(mac.hidden_states.view(E, J, -1))  # post-update h_t
         T32 = mac.last_actions_T32 if mac.last_actions_T32 is not None else T64.squeeze(-1).to(torch.int32)
@@ -224,14 +230,61 @@ class BatchedEpisodeRunner:
         if store and not test_mode:
             self.buffer.store_episodes_batched(self.stage, self.batch_envs)
 
+    # ---- HIP-graph replay of a whole episode batch ----
+    def enable_graph(self):
+        """Capture reset + all ``episode_limit`` batched steps (~25 launches each) as ONE HIP graph.
+        Kernel arguments are frozen at capture, so the two per-step scalars that change between episodes —
+        the exploration probability and the Philox call counter of the select kernel — are read from device
+        memory (``_eps_sched[t]``, ``_ctr_base``) that ``rollout_graphed`` refreshes before each replay."""
+        T = self.episode_limit
+        dev = self.device
+        self._eps_sched = torch.zeros(T, dtype=torch.float32, device=dev)
+        self._ctr_base = torch.zeros(1, dtype=torch.int64, device=dev)
+        t_env0, ep0 = self.t_env, self._ep
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):  # warm-up outside capture
+            self._rollout_body(device_schedule=True)
+        torch.cuda.current_stream(dev).wait_stream(s)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._rollout_body(device_schedule=True)
+        self.t_env, self._ep = t_env0, ep0
+        self.mac.device_schedule = None
+
+    def _rollout_body(self, device_schedule=False):
+        T = self.episode_limit
+        self.begin_episodes()
+        for t in range(T):
+            if device_schedule:
+                self.mac.device_schedule = (self._eps_sched[t:t + 1], self._ctr_base, t + 1)
+            self.step(t, test_mode=False)
+        self.mac.device_schedule = None
+
+    def rollout_graphed(self):
+        """Enqueue one whole episode batch by replaying the captured graph (training mode)."""
+        T = self.episode_limit
+        sel = self.mac.action_selector
+        eps = np.empty(T, dtype=np.float32)
+        for t in range(T):
+            eps[t] = sel.anneal(self.t_env + t, test_mode=False)
+        self._eps_sched.copy_(torch.from_numpy(eps))
+        self._ep += 1
+        self._ctr_base.fill_(self._ep * (T + 1))
+        self._graph.replay()
+        self.t_env += T
+
     def run(self, test_mode=False, store=True, sync_stats=True):
         """One batch of E episodes.  Returns the reference's ``run_info`` keys as means over the E
         episodes (one host sync at the very end; pass ``sync_stats=False`` to get 0-dim tensors)."""
         st = self.stage
         T, E, J = self.episode_limit, self.batch_envs, self.n_agents
-        self.begin_episodes()
-        for t in range(T):
-            self.step(t, test_mode=test_mode)
+        if getattr(self, "_graph", None) is not None and not test_mode:
+            self.rollout_graphed()
+        else:
+            self.begin_episodes()
+            for t in range(T):
+                self.step(t, test_mode=test_mode)
         self.end_episodes(test_mode=test_mode, store=store)
         ret = st["reward"].sum(dim=(0, 2))  # [E]
         stats = {

@@ -316,7 +316,7 @@ def test_graphed_train_equals_eager_train():
         return mac, learner, buf
     mac_e, eager, buf_e = build()
     mac_g, graphed, buf_g = build()
-    graphed.enable_graphs(buf_g, B, warmup_iters=0)   # no warm-up updates so both start from the same weights
+    graphed.enable_graphs(buf_g, B)   # warm-up updates are undone in place: both start from the same state
     rng = np.random.default_rng(1)
     for step in range(7):
         idx = rng.choice(N, B, replace=False)
@@ -329,3 +329,43 @@ def test_graphed_train_equals_eager_train():
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-6, rtol=0, err_msg=k)
     for (k, a), b in zip(eager.target_qmix_net.state_dict().items(), graphed.target_qmix_net.state_dict().values()):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-6, rtol=0, err_msg=k)
+
+
+def test_graphed_rollout_equals_eager_rollout():
+    """One HIP-graph launch per episode batch == step-by-step launches: identical actions, rewards,
+    hidden states over two consecutive episode batches (epsilon annealing + Philox counters advance)."""
+    from macjd_amd.core.mac import BasicMAC
+    from macjd_amd.runners.episode_runner import BatchedEpisodeRunner
+    from macjd_amd.simulation.environment import BatchedElectromagneticEnvironment
+    from macjd_amd.utils.replay_buffer import EpisodeReplayBuffer
+    sc, _ = load_scenario("3j4r")
+    E = 512
+    def build():
+        env = BatchedElectromagneticEnvironment(scenario=sc, batch_envs=E, device=DEV, seed=5)
+        info = env.get_env_info()
+        d = dict(J=info["n_agents"], A=info["n_actions"], S=info["state_shape"], H=64)
+        args = _gpu_args(d, episode_limit=info["episode_limit"], buffer_size=2 * E, epsilon_start=0.6,
+                         epsilon_anneal_time=300)
+        args.env_info = info
+        torch.manual_seed(3)
+        with quiet():
+            mac = BasicMAC(info["obs_shape"], args)
+            mac.cuda()
+            buf = EpisodeReplayBuffer(args)
+        return BatchedEpisodeRunner(env, mac, buf, args), buf, mac
+    r_e, b_e, m_e = build()
+    r_g, b_g, m_g = build()
+    r_g.enable_graph()
+    for ep in range(2):
+        ie = r_e.run(sync_stats=True)
+        ig = r_g.run(sync_stats=True)
+        assert ie["episode_return"] == pytest.approx(ig["episode_return"], rel=1e-6)
+        np.testing.assert_allclose(ie["action_distribution"], ig["action_distribution"], atol=1e-7)
+    assert r_e.t_env == r_g.t_env == 200
+    assert m_e.action_selector.epsilon == pytest.approx(m_g.action_selector.epsilon)
+    for k in b_e.buffers:
+        a, b = b_e.buffers[k], b_g.buffers[k]
+        if a.dtype.is_floating_point:
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-6, rtol=0, err_msg=k)
+        else:
+            assert torch.equal(a, b), k
