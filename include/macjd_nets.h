@@ -8,7 +8,9 @@
  *                        (core/qmix.py:256-274), both built on RNNAgent.get_q_value_for_action
  *                        (core/networks.py:131-180);
  *   macjd_gru_sequence   the learner's `for t in range(max_seq_len)` GRU unroll
- *                        (core/qmix.py:241-253 -> core/networks.py:88-114).
+ *                        (core/qmix.py:241-253 -> core/networks.py:88-114);
+ *   macjd_mixer_tail_*   QMixer.forward after the hyper-network GEMMs, and its backward
+ *                        (core/networks.py:283-315).
  * Device pointers, element strides, no torch / HIP types; asynchronous on the given stream.
  */
 #ifndef MACJD_NETS_H
@@ -77,6 +79,34 @@ typedef struct macjd_gru_io {
 } macjd_gru_io;
 
 int macjd_gru_sequence(const macjd_gru_io* io, void* hip_stream);
+
+/*
+ * QMixer.forward after the hyper-network GEMMs (reference core/networks.py:283-315), per row m:
+ *   w1 = clamp(w1_raw, 0, 5) [J,Em]   b1 = clamp(b1_raw, -5, 5) [Em]   wf = clamp(wf_raw, 0, 5) [Em]
+ *   v = clamp(v_raw, -5, 5)           hid = q . w1 + b1                y = ELU(hid) . wf + v
+ * (torch.bmm([M,1,J],[M,J,Em]) / F.elu / torch.bmm([M,1,Em],[M,Em,1]) in the reference) and its backward
+ * (clamp passes the gradient where min <= x <= max, like torch.clamp).  All tensors contiguous float32.
+ * Forward needs q, w1_raw, b1_raw, wf_raw, v_raw, y.  Backward additionally gy and the five gradient outputs.
+ */
+typedef struct macjd_mixer_io {
+    int64_t M;              /* rows = B * (T-1) */
+    int32_t J, Em;          /* agents, mixing_embed_dim */
+    const float* q;         /* [M,J]    */
+    const float* w1_raw;    /* [M,J*Em] hyper_w_1 output   */
+    const float* b1_raw;    /* [M,Em]   hyper_b_1 output   */
+    const float* wf_raw;    /* [M,Em]   hyper_w_final output */
+    const float* v_raw;     /* [M]      V output           */
+    float* y;               /* [M]      Q_tot (forward out) */
+    const float* gy;        /* [M]      dL/dy (backward in) */
+    float* gq;              /* [M,J]    (backward outs)    */
+    float* gw1_raw;         /* [M,J*Em] */
+    float* gb1_raw;         /* [M,Em]   */
+    float* gwf_raw;         /* [M,Em]   */
+    float* gv_raw;          /* [M]      */
+} macjd_mixer_io;
+
+int macjd_mixer_tail_forward(const macjd_mixer_io* io, void* hip_stream);
+int macjd_mixer_tail_backward(const macjd_mixer_io* io, void* hip_stream);
 
 #ifdef __cplusplus
 }

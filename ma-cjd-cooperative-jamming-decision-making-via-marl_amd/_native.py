@@ -22,7 +22,7 @@ EXPORTS = [
     "macjd_abi_version", "macjd_last_error", "macjd_device_count",
     "macjd_scenario_create", "macjd_scenario_destroy", "macjd_scenario_dims",
     "macjd_env_reset", "macjd_env_step", "macjd_env_step_timed",
-    "macjd_qhead_select", "macjd_gru_sequence",
+    "macjd_qhead_select", "macjd_gru_sequence", "macjd_mixer_tail_forward", "macjd_mixer_tail_backward",
 ]
 
 
@@ -79,6 +79,17 @@ class GruIO(ctypes.Structure):
     ]
 
 
+class MixerIO(ctypes.Structure):
+    """ctypes mirror of ``macjd_mixer_io`` (include/macjd_nets.h)."""
+    _fields_ = [
+        ("M", ctypes.c_int64), ("J", ctypes.c_int32), ("Em", ctypes.c_int32),
+        ("q", ctypes.c_void_p), ("w1_raw", ctypes.c_void_p), ("b1_raw", ctypes.c_void_p),
+        ("wf_raw", ctypes.c_void_p), ("v_raw", ctypes.c_void_p), ("y", ctypes.c_void_p),
+        ("gy", ctypes.c_void_p), ("gq", ctypes.c_void_p), ("gw1_raw", ctypes.c_void_p),
+        ("gb1_raw", ctypes.c_void_p), ("gwf_raw", ctypes.c_void_p), ("gv_raw", ctypes.c_void_p),
+    ]
+
+
 _lib: Optional[ctypes.CDLL] = None
 
 
@@ -116,6 +127,9 @@ def load() -> ctypes.CDLL:
     lib.macjd_qhead_select.argtypes = [ctypes.POINTER(QheadIO), ctypes.c_void_p]
     lib.macjd_gru_sequence.restype = ctypes.c_int
     lib.macjd_gru_sequence.argtypes = [ctypes.POINTER(GruIO), ctypes.c_void_p]
+    for name in ("macjd_mixer_tail_forward", "macjd_mixer_tail_backward"):
+        getattr(lib, name).restype = ctypes.c_int
+        getattr(lib, name).argtypes = [ctypes.POINTER(MixerIO), ctypes.c_void_p]
     if lib.macjd_abi_version() != ABI_VERSION:
         raise NativeLibraryError(f"{LIB_NAME}: ABI version {lib.macjd_abi_version()} != expected {ABI_VERSION}")
     _lib = lib

@@ -17,8 +17,9 @@ What is different is HOW the hot calls are evaluated:
   epilogue runs in one fused kernel (csrc/macjd_nets.hip) that never materialises the [N, A, H]
   tensor; results match the per-action loop to ~1e-6 (different summation order).
 * ``QMixer.forward`` keeps the reference arithmetic (LayerNorm -> 4 hyper-networks -> clamp ->
-  bmm/ELU/bmm, core/networks.py:250-315) but evaluates the two tiny batched products as broadcast
-  multiplies + reductions instead of ``torch.bmm`` over [M,1,J]x[M,J,Em] matrices.
+  bmm/ELU/bmm, core/networks.py:250-315); everything after the hyper-network GEMMs (4 clamps, the two
+  tiny batched products, ELU) and its backward is one fused kernel each way on a HIP device
+  (``ops.mixer_tail``), instead of ~12 / ~25 elementwise + reduction launches.
 """
 from __future__ import annotations
 
@@ -134,13 +135,9 @@ class QMixer(nn.Module):
         the reference: [B, T, 1] for [B, T, J] inputs, [B, 1] for [B, J]."""
         batch_size = agent_qs.size(0)
         s = self.state_norm(states.reshape(-1, self.state_dim))
-        q = agent_qs.reshape(-1, self.n_agents, 1)
-        w1 = torch.clamp(self.hyper_w_1(s), min=0.0, max=5.0).view(-1, self.n_agents, self.embed_dim)
-        b1 = torch.clamp(self.hyper_b_1(s), min=-5.0, max=5.0)
-        w_final = torch.clamp(self.hyper_w_final(s), min=0.0, max=5.0)
-        v = torch.clamp(self.V(s), min=-5.0, max=5.0)
-        hidden = F.elu((q * w1).sum(dim=1) + b1)          # bmm([M,1,J],[M,J,Em]) + b1
-        y = (hidden * w_final).sum(dim=1, keepdim=True) + v  # bmm([M,1,Em],[M,Em,1]) + v
+        q = agent_qs.reshape(-1, self.n_agents)
+        # clamp -> bmm -> ELU -> bmm (+ its backward) is one fused kernel on a HIP device (ops.mixer_tail)
+        y = ops.mixer_tail(q, self.hyper_w_1(s), self.hyper_b_1(s), self.hyper_w_final(s), self.V(s))
         q_tot = y.view(batch_size, -1, 1)
         if q_tot.shape[1] == 1:
             q_tot = q_tot.squeeze(1)

@@ -191,7 +191,8 @@ class QMixLearner:
             raise RuntimeError("enable_graphs: the replay buffer is empty")
 
         def body_a():
-            b = {k: v.index_select(0, self._g_idx) for k, v in buffer.buffers.items()}
+            b = {k: v.index_select(0, self._g_idx) for k, v in buffer.buffers.items()
+                 if k != "avail_actions"}  # the update never reads the mask (qmix.py:141-142 is commented out)
             return self._forward_backward(b, self._g_T, validate_actions=False)
 
         # Eager warm-up on a side stream: allocates the optimiser state BEFORE capture (state created during

@@ -304,3 +304,101 @@ extern "C" int macjd_gru_sequence(const macjd_gru_io* io, void* hip_stream) {
     if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
     return MACJD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// QMix mixer tail: clamp -> (q . w1 + b1) -> ELU -> (. wf + v), forward and backward.
+// One wave per row m, lane = embed column e (Em = 64 in the reference config; other sizes loop in chunks
+// of 64).  Every load is a contiguous 256-B row segment (w1_raw[m, j, :], b1_raw[m, :], wf_raw[m, :]); the
+// two contractions are J fused multiply-adds per lane plus ONE wave reduction (forward) / J wave
+// reductions (backward, dL/dq_j).  Replaces ~12 (forward) / ~25 (backward) elementwise + reduce launches
+// per mixer call of the unfused form.
+namespace macjd {
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+template <bool BACKWARD>
+__global__ void __launch_bounds__(256) mixer_tail_kernel(const macjd_mixer_io io) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (m >= io.M) return;  // whole waves exit together (one row per wave)
+    const int J = io.J, Em = io.Em;
+    const float* __restrict__ q = io.q + m * J;
+    const float* __restrict__ w1r = io.w1_raw + m * (int64_t)J * Em;
+    float ysum = 0.0f;
+    float gq_acc[MACJD_MAX_JAMMERS];
+    if (BACKWARD) {
+#pragma unroll
+        for (int j = 0; j < MACJD_MAX_JAMMERS; ++j) gq_acc[j] = 0.0f;
+    }
+    const float gy = BACKWARD ? io.gy[m] : 0.0f;
+    for (int e = lane; e < ((Em + 63) & ~63); e += 64) {
+        const bool live = e < Em;
+        const float b1r = live ? io.b1_raw[m * Em + e] : 0.0f;
+        const float wfr = live ? io.wf_raw[m * Em + e] : 0.0f;
+        float hid = clampf(b1r, -5.0f, 5.0f);
+        for (int j = 0; j < J; ++j) {
+            const float w = live ? clampf(w1r[(int64_t)j * Em + e], 0.0f, 5.0f) : 0.0f;
+            hid = fmaf(q[j], w, hid);                          // bmm(agent_qs, w1) + b1, networks.py:304
+        }
+        const float h = hid > 0.0f ? hid : expm1f(hid);        // F.elu
+        const float wf = clampf(wfr, 0.0f, 5.0f);
+        if (!BACKWARD) {
+            ysum += live ? h * wf : 0.0f;                      // bmm(hidden, w_final), networks.py:307
+        } else if (live) {
+            const float ghid = gy * wf * (hid > 0.0f ? 1.0f : h + 1.0f);   // ELU'(x) = exp(x) = elu(x) + 1 for x <= 0
+            io.gwf_raw[m * Em + e] = (wfr >= 0.0f && wfr <= 5.0f) ? gy * h : 0.0f;
+            io.gb1_raw[m * Em + e] = (b1r >= -5.0f && b1r <= 5.0f) ? ghid : 0.0f;
+            for (int j = 0; j < J; ++j) {
+                const float wr = w1r[(int64_t)j * Em + e];
+                io.gw1_raw[m * (int64_t)J * Em + (int64_t)j * Em + e] = (wr >= 0.0f && wr <= 5.0f) ? ghid * q[j] : 0.0f;
+                gq_acc[j] += ghid * clampf(wr, 0.0f, 5.0f);
+            }
+        }
+    }
+    if (!BACKWARD) {
+        const float tot = wave_sum(ysum);
+        if (lane == 0) io.y[m] = tot + clampf(io.v_raw[m], -5.0f, 5.0f);
+    } else {
+        for (int j = 0; j < J; ++j) {
+            const float t = wave_sum(gq_acc[j]);
+            if (lane == 0) io.gq[m * J + j] = t;
+        }
+        if (lane == 0) {
+            const float vr = io.v_raw[m];
+            io.gv_raw[m] = (vr >= -5.0f && vr <= 5.0f) ? gy : 0.0f;
+        }
+    }
+}
+
+static int mixer_launch(const macjd_mixer_io* io, void* hip_stream, bool backward) {
+    if (!io) return set_nets_err(MACJD_EINVAL, "macjd_mixer_tail: NULL io");
+    if (io->M < 0 || io->J < 1 || io->J > MACJD_MAX_JAMMERS || io->Em < 1)
+        return set_nets_err(MACJD_EINVAL, "macjd_mixer_tail: bad M / J / Em");
+    if (!io->q || !io->w1_raw || !io->b1_raw || !io->wf_raw || !io->v_raw)
+        return set_nets_err(MACJD_EINVAL, "macjd_mixer_tail: NULL input");
+    if (!backward && !io->y) return set_nets_err(MACJD_EINVAL, "macjd_mixer_tail_forward: NULL y");
+    if (backward && (!io->gy || !io->gq || !io->gw1_raw || !io->gb1_raw || !io->gwf_raw || !io->gv_raw))
+        return set_nets_err(MACJD_EINVAL, "macjd_mixer_tail_backward: NULL gradient pointer");
+    if (io->M == 0) return MACJD_OK;
+    const dim3 g((unsigned)((io->M + 3) / 4)), b(256);
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (backward) hipLaunchKernelGGL((mixer_tail_kernel<true>), g, b, 0, s, *io);
+    else hipLaunchKernelGGL((mixer_tail_kernel<false>), g, b, 0, s, *io);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
+    return MACJD_OK;
+}
+
+}  // namespace macjd
+
+extern "C" int macjd_mixer_tail_forward(const macjd_mixer_io* io, void* hip_stream) {
+    return macjd::mixer_launch(io, hip_stream, false);
+}
+extern "C" int macjd_mixer_tail_backward(const macjd_mixer_io* io, void* hip_stream) {
+    return macjd::mixer_launch(io, hip_stream, true);
+}

@@ -172,3 +172,61 @@ def gru_sequence_multi(gis, w_hhs, b_hhs, h0s=None):
         with torch.cuda.device(gis[0].device):
             _native.check(lib.macjd_gru_sequence(ctypes.byref(io), _stream(gis[0])), "macjd_gru_sequence")
     return outs
+
+
+# ---------------------------------------------------------------------------------------------
+# QMix mixer tail (reference core/networks.py:283-315)
+def mixer_tail_reference(q, w1_raw, b1_raw, wf_raw, v_raw):
+    """Stock-torch form: q [M,J], w1_raw [M,J*Em], b1_raw [M,Em], wf_raw [M,Em], v_raw [M,1] -> y [M,1]."""
+    M, J = q.shape
+    Em = b1_raw.shape[1]
+    w1 = torch.clamp(w1_raw, min=0.0, max=5.0).view(M, J, Em)
+    b1 = torch.clamp(b1_raw, min=-5.0, max=5.0)
+    wf = torch.clamp(wf_raw, min=0.0, max=5.0)
+    v = torch.clamp(v_raw, min=-5.0, max=5.0)
+    hidden = F.elu((q.unsqueeze(2) * w1).sum(dim=1) + b1)
+    return (hidden * wf).sum(dim=1, keepdim=True) + v
+
+
+def _mixer_io(q, w1_raw, b1_raw, wf_raw, v_raw):
+    io = _native.MixerIO()
+    io.M, io.J, io.Em = q.shape[0], q.shape[1], b1_raw.shape[1]
+    io.q, io.w1_raw, io.b1_raw = q.data_ptr(), w1_raw.data_ptr(), b1_raw.data_ptr()
+    io.wf_raw, io.v_raw = wf_raw.data_ptr(), v_raw.data_ptr()
+    return io
+
+
+class _MixerTailHip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, w1_raw, b1_raw, wf_raw, v_raw):
+        lib = _native.load()
+        args = [t.detach().float().contiguous() for t in (q, w1_raw, b1_raw, wf_raw, v_raw)]
+        y = torch.empty((q.shape[0], 1), dtype=torch.float32, device=q.device)
+        io = _mixer_io(*args)
+        io.y = y.data_ptr()
+        with torch.cuda.device(q.device):
+            _native.check(lib.macjd_mixer_tail_forward(ctypes.byref(io), _stream(q)), "macjd_mixer_tail_forward")
+        ctx.save_for_backward(*args)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _native.load()
+        q, w1_raw, b1_raw, wf_raw, v_raw = ctx.saved_tensors
+        gy = gy.detach().float().contiguous()
+        gq, gw1, gb1 = torch.empty_like(q), torch.empty_like(w1_raw), torch.empty_like(b1_raw)
+        gwf, gv = torch.empty_like(wf_raw), torch.empty_like(v_raw)
+        io = _mixer_io(q, w1_raw, b1_raw, wf_raw, v_raw)
+        io.gy, io.gq, io.gw1_raw = gy.data_ptr(), gq.data_ptr(), gw1.data_ptr()
+        io.gb1_raw, io.gwf_raw, io.gv_raw = gb1.data_ptr(), gwf.data_ptr(), gv.data_ptr()
+        with torch.cuda.device(q.device):
+            _native.check(lib.macjd_mixer_tail_backward(ctypes.byref(io), _stream(q)), "macjd_mixer_tail_backward")
+        return gq, gw1, gb1, gwf, gv
+
+
+def mixer_tail(q, w1_raw, b1_raw, wf_raw, v_raw):
+    """y = ELU(q . clamp(w1) + clamp(b1)) . clamp(wf) + clamp(v), [M,1]; fused HIP forward/backward on a
+    HIP device (differentiable), stock torch ops for host tensors."""
+    if not q.is_cuda:
+        return mixer_tail_reference(q, w1_raw, b1_raw, wf_raw, v_raw)
+    return _MixerTailHip.apply(q, w1_raw, b1_raw, wf_raw, v_raw)
