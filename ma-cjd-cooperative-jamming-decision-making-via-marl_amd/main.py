@@ -1,0 +1,313 @@
+"""Training driver: the reference's ``main.py`` schedule on the MI355X hot path.
+
+Same entry points and behaviour as reference ``main.py:50-328``:
+  ``load_config(config_name, config_dir) -> SimpleNamespace``; ``run(args)``; CLI ``--config --env-config
+  --device``; seeds (np / torch = ``args.seed``); env info copied into ``args``; the
+  episodes-then-train cadence (``main.py:191-226``); the console block and the 13 + A scalar tags
+  (``main.py:252-278``); checkpoints ``<save_model_dir>/<test_name>/step_<N>/{agent,qmix_net,optimizer}.pth``
+  every ``save_interval`` episodes once ``total_steps > start_training_steps`` (``main.py:283-289``).
+
+What is added (build flags, all optional):
+  ``batch_envs``  (default 1)  E > 1 switches to the batched device-resident runner: one ``runner.run()`` is E
+                  episodes.  The learner then does ``episode_len // train_interval`` updates per ROLLOUT (the
+                  reference does that many per episode; with ``batch_envs = 1`` the two coincide exactly).
+  ``hip_graphs``  (default True on a HIP device with batch_envs > 1) replay rollouts / updates from HIP graphs.
+  ``--resume DIR`` restores agent, mixer, optimiser and ``trainer_state.json`` (env steps, episodes, epsilon
+                  clock, learner step counters) — the reference saves the optimiser but never loads it and has
+                  no resume path (``core/qmix.py:317-333``).
+  ``test_interval`` / ``test_nepisodes`` (present but unread in the reference's ``default.yaml:81-83``): greedy
+                  evaluation episodes reporting return, radar lock fraction and mean power (the paper's
+                  metrics, ``docs/impadd.md:60-64``).
+  TensorBoard is optional (it is not installed in every image): scalars always go to ``scalars.jsonl`` under
+  the run's log directory, and to a ``SummaryWriter`` as well when ``torch.utils.tensorboard`` imports.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import time
+from collections import deque
+from datetime import datetime
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import yaml
+
+from .core.mac import BasicMAC
+from .core.qmix import QMixLearner
+from .runners.episode_runner import BatchedEpisodeRunner, EpisodeRunner
+from .utils.replay_buffer import EpisodeReplayBuffer
+
+
+def load_config(config_name="default", config_dir="config"):
+    """YAML -> flat SimpleNamespace (main.py:50-79)."""
+    path = os.path.join(config_dir, f"{config_name}.yaml")
+    try:
+        with open(path, "r") as f:
+            config_dict = yaml.safe_load(f)
+        print(f"Configuration loaded successfully from {path}")
+        return SimpleNamespace(**config_dict)
+    except FileNotFoundError:
+        print(f"Error: Configuration file not found at {path}")
+        raise
+    except yaml.YAMLError as e:
+        print(f"Error parsing configuration file {path}: {e}")
+        raise
+
+
+class ScalarLog:
+    """``add_scalar(tag, value, step)`` sink: always ``scalars.jsonl``; TensorBoard too when available."""
+
+    def __init__(self, log_dir):
+        os.makedirs(log_dir, exist_ok=True)
+        self.path = os.path.join(log_dir, "scalars.jsonl")
+        self._f = open(self.path, "a")
+        self._tb = None
+        try:
+            from torch.utils.tensorboard import SummaryWriter  # noqa: WPS433 (optional dependency)
+            self._tb = SummaryWriter(log_dir=log_dir)
+        except Exception:
+            self._tb = None
+
+    def add_scalar(self, tag, value, step):
+        self._f.write(json.dumps({"tag": tag, "value": float(value), "step": int(step)}) + "\n")
+        if self._tb is not None:
+            self._tb.add_scalar(tag, value, step)
+
+    def close(self):
+        self._f.close()
+        if self._tb is not None:
+            self._tb.close()
+
+
+def _pick_device(args):
+    requested = str(getattr(args, "device_request", getattr(args, "device", "cuda"))).lower()
+    if requested.startswith("cuda") and torch.cuda.is_available():
+        device = torch.device("cuda")
+    else:
+        if requested.startswith("cuda"):
+            print("Warning: CUDA requested but not available. Falling back to CPU.")
+        device = torch.device("cpu")
+    args.device = str(device)
+    args.use_cuda = device.type == "cuda"
+    return device
+
+
+def build_components(args, sim_config_path):
+    """env, mac, buffer, learner, runner — single-env reference protocol or the batched hot path."""
+    batch_envs = int(getattr(args, "batch_envs", 1) or 1)
+    if batch_envs > 1:
+        from .simulation.environment import BatchedElectromagneticEnvironment
+        env = BatchedElectromagneticEnvironment(args, sim_config_path, batch_envs=batch_envs, seed=args.seed,
+                                                env_offset=int(getattr(args, "env_offset", 0)), verbose=True)
+    else:
+        from .simulation.environment import ElectromagneticEnvironment
+        env = ElectromagneticEnvironment(config=args, sim_config_path=sim_config_path)
+    env_info = env.get_env_info()
+    args.n_agents = env_info["n_agents"]            # main.py:141-147
+    args.n_actions = env_info["n_actions"]
+    args.state_shape = env_info["state_shape"]
+    args.obs_shape = env_info.get("obs_shape", args.state_shape)
+    args.episode_limit = env_info["episode_limit"]
+    args.env_info = env_info
+    if batch_envs > 1 and args.buffer_size < batch_envs:
+        raise ValueError(f"buffer_size ({args.buffer_size}) must hold at least one rollout of {batch_envs} episodes")
+    mac = BasicMAC(input_shape=args.obs_shape, args=args)
+    buffer = EpisodeReplayBuffer(args=args)
+    learner = QMixLearner(mac, args=args)
+    if args.use_cuda:
+        mac.cuda()
+    runner = (BatchedEpisodeRunner if batch_envs > 1 else EpisodeRunner)(env=env, mac=mac, buffer=buffer, args=args)
+    return env, mac, buffer, learner, runner
+
+
+def save_checkpoint(learner, runner, save_dir, episode, total_steps):
+    """Reference files (qmix.py:300-315) + trainer_state.json for resume."""
+    os.makedirs(save_dir, exist_ok=True)
+    learner.save_models(save_dir)
+    state = {"episode": episode, "total_steps": total_steps, "t_env": runner.t_env,
+             "train_step": learner.train_step, "last_target_update_step": learner.last_target_update_step,
+             "epsilon": learner.mac.action_selector.epsilon}
+    with open(os.path.join(save_dir, "trainer_state.json"), "w") as f:
+        json.dump(state, f)
+
+
+def load_checkpoint(learner, runner, load_dir):
+    learner.load_models(load_dir)
+    opt_path = os.path.join(load_dir, "optimizer.pth")
+    if os.path.exists(opt_path):
+        learner.optimizer.load_state_dict(torch.load(opt_path, map_location=learner.device, weights_only=True))
+    state = {"episode": 0, "total_steps": 0}
+    st_path = os.path.join(load_dir, "trainer_state.json")
+    if os.path.exists(st_path):
+        with open(st_path) as f:
+            state = json.load(f)
+        runner.t_env = int(state.get("t_env", 0))
+        learner.train_step = int(state.get("train_step", 0))
+        learner.last_target_update_step = int(state.get("last_target_update_step", 0))
+        learner.mac.action_selector.epsilon = float(state.get("epsilon", learner.mac.action_selector.epsilon))
+    return state
+
+
+def evaluate(runner, n_episodes):
+    """Greedy (test_mode) episodes: mean return, radar lock fraction and mean normalised power."""
+    rets, locks, powers = [], [], []
+    n_radars = runner.env.num_radars
+    rd_pen = np.asarray(runner.env.scenario.tables["radar_rd_pen"])
+    runs = max(1, int(np.ceil(n_episodes / getattr(runner, "batch_envs", 1))))
+    for _ in range(runs):
+        info = runner.run(test_mode=True)
+        rets.append(info["episode_return"])
+        powers.append(info["avg_power_overall"])
+        # r_d is the sum of per-radar penalties over tracking radars; with the mean penalty this gives the
+        # mean fraction of radars locked per step
+        locks.append(float(info["avg_r_d"]) / float(rd_pen.mean()) / n_radars if rd_pen.mean() != 0 else 0.0)
+    return {"return": float(np.mean(rets)), "lock_fraction": float(np.mean(locks)), "power": float(np.mean(powers))}
+
+
+def run(args):
+    device = _pick_device(args)
+    print(f"Using device: {args.device}")
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+    if args.use_cuda:
+        torch.cuda.manual_seed(args.seed)
+    test_name = getattr(args, "test_name", "ma_cjd_test")
+    run_name = f"run_{datetime.now().strftime('%Y%m%d_%H%M%S')}"
+    log_dir = os.path.join(getattr(args, "results_path", "logs") or "logs", test_name, run_name)
+    writer = ScalarLog(log_dir)
+    print(f"Logs will be saved to: {log_dir}")
+
+    sim_config_path = getattr(args, "sim_config_path", None) or os.path.join("config", f"{args.env_config}.yaml")
+    env, mac, buffer, learner, runner = build_components(args, sim_config_path)
+    batch_envs = int(getattr(args, "batch_envs", 1) or 1)
+    episodes_per_run = batch_envs
+    use_graphs = bool(getattr(args, "hip_graphs", True)) and args.use_cuda and batch_envs > 1
+
+    episode, total_steps = 0, 0
+    if getattr(args, "resume", None):
+        st = load_checkpoint(learner, runner, args.resume)
+        episode, total_steps = int(st.get("episode", 0)), int(st.get("total_steps", 0))
+        print(f"Resumed from {args.resume}: episode {episode}, env steps {total_steps}")
+
+    n_upd = args.log_interval * (args.episode_limit // args.train_interval)
+    log_stats = {k: deque(maxlen=args.log_interval) for k in
+                 ("episode_return", "episode_length", "avg_step_reward", "reward_r_d", "reward_r_p", "reward_r_j",
+                  "avg_power", "action_dist")}
+    log_stats.update({k: deque(maxlen=n_upd) for k in ("loss", "grad_norm", "eval_qtot_avg", "target_qtot_avg")})
+    start_time = last_log_time = time.time()
+    next_test = total_steps + getattr(args, "test_interval", 0) if getattr(args, "test_interval", 0) else None
+    graphs_on = False
+    print("Starting training...")
+    while total_steps < args.total_env_steps:
+        run_info = runner.run(test_mode=False)                                   # main.py:193
+        episode += episodes_per_run
+        current_episode_steps = run_info["episode_length"]
+        total_steps += current_episode_steps * episodes_per_run
+        log_stats["episode_return"].append(run_info["episode_return"])
+        log_stats["episode_length"].append(current_episode_steps)
+        log_stats["avg_step_reward"].append(run_info.get("avg_step_reward", 0))
+        log_stats["reward_r_d"].append(run_info.get("avg_r_d", 0))
+        log_stats["reward_r_p"].append(run_info.get("avg_r_p", 0))
+        log_stats["reward_r_j"].append(run_info.get("avg_r_j", 0))
+        log_stats["avg_power"].append(run_info.get("avg_power_overall", 0))
+        if "action_distribution" in run_info:
+            log_stats["action_dist"].append(np.asarray(run_info["action_distribution"]))
+
+        if buffer.current_size >= args.batch_size and total_steps > args.start_training_steps:   # main.py:212
+            if use_graphs and not graphs_on:
+                learner.enable_graphs(buffer, args.batch_size)
+                runner.enable_graph()
+                graphs_on = True
+            num_train_steps = current_episode_steps // args.train_interval
+            pending = []
+            for _ in range(num_train_steps):
+                if graphs_on:
+                    pending.append(learner.train_from_buffer(sync_stats=False))
+                else:
+                    batch = buffer.sample(args.batch_size)
+                    if batch is not None:
+                        pending.append(learner.train(batch, {"total_steps": total_steps}, sync_stats=not args.use_cuda))
+            if pending:  # one host sync for the whole block of updates
+                if torch.is_tensor(pending[0]["loss"]):
+                    keys = list(pending[0].keys())
+                    vals = torch.stack([torch.stack([torch.as_tensor(p[k], device=device, dtype=torch.float32).reshape(())
+                                                     for k in keys]) for p in pending]).tolist()
+                    pending = [dict(zip(keys, v)) for v in vals]
+                for st in pending:
+                    for k in ("loss", "grad_norm", "eval_qtot_avg", "target_qtot_avg"):
+                        log_stats[k].append(st[k])
+                writer.add_scalar("Loss/train_episode_avg", float(np.mean([p["loss"] for p in pending])), total_steps)
+
+        if next_test is not None and total_steps >= next_test:
+            ev = evaluate(runner, getattr(args, "test_nepisodes", 20))
+            writer.add_scalar("Test/Avg_Return", ev["return"], total_steps)
+            writer.add_scalar("Test/Lock_Fraction", ev["lock_fraction"], total_steps)
+            writer.add_scalar("Test/Avg_Power", ev["power"], total_steps)
+            print(f"  [eval @ {total_steps}] return {ev['return']:.2f} | lock fraction {ev['lock_fraction']:.3f} | "
+                  f"power {ev['power']:.3f}")
+            next_test += args.test_interval
+
+        now = time.time()
+        if (now - last_log_time) >= args.log_interval_seconds or total_steps >= args.total_env_steps:   # main.py:231
+            m = lambda k: float(np.mean(log_stats[k])) if log_stats[k] else 0.0
+            dist = np.mean(np.array(log_stats["action_dist"]), axis=0) if log_stats["action_dist"] else np.zeros(args.n_actions)
+            print(f"Steps: {total_steps}/{args.total_env_steps} | Episodes: {episode} | Time: {now - start_time:.2f}s")
+            print(f"  Avg Return (last {len(log_stats['episode_return'])} eps): {m('episode_return'):.2f} | "
+                  f"Avg Length: {m('episode_length'):.1f} | Avg Loss: {m('loss'):.4f}")
+            print(f"  Avg Step Reward (last {len(log_stats['avg_step_reward'])} eps): {m('avg_step_reward'):.4f}")
+            print(f"  Avg Rewards (r_d/r_p/r_j): {m('reward_r_d'):.4f} / {m('reward_r_p'):.4f} / {m('reward_r_j'):.4f}")
+            print(f"  Avg QTot (Eval/Target): {m('eval_qtot_avg'):.4f} / {m('target_qtot_avg'):.4f} | "
+                  f"Avg Grad Norm: {m('grad_norm'):.4f}")
+            print(f"  Avg Power: {m('avg_power'):.3f} | Action Dist: [{' / '.join(f'{p:.2f}' for p in dist)}] "
+                  f"(0=Idle, 1=S0, 2=D0, ...)")
+            print(f"  Buffer Size: {len(buffer)}")
+            print(f"  Epsilon: {mac.action_selector.epsilon:.3f}")
+            for tag, val in (("Perf/Avg_Return", m("episode_return")), ("Perf/Avg_Length", m("episode_length")),
+                             ("Perf/Avg_Step_Reward", m("avg_step_reward")), ("Loss/train_avg", m("loss")),
+                             ("Params/Epsilon", mac.action_selector.epsilon), ("Params/Buffer_Size", len(buffer)),
+                             ("Stats/grad_norm", m("grad_norm")), ("QValues/eval_qtot_avg", m("eval_qtot_avg")),
+                             ("QValues/target_qtot_avg", m("target_qtot_avg")), ("Rewards/r_d_avg", m("reward_r_d")),
+                             ("Rewards/r_p_avg", m("reward_r_p")), ("Rewards/r_j_avg", m("reward_r_j")),
+                             ("Perf/Avg_Power", m("avg_power"))):
+                writer.add_scalar(tag, val, total_steps)
+            for act_idx, act_prob in enumerate(dist):
+                writer.add_scalar(f"ActionDist/Action_{act_idx}", act_prob, total_steps)
+            last_log_time = now
+
+        boundary = (episode // args.save_interval) != ((episode - episodes_per_run) // args.save_interval)
+        if args.save_model and (boundary or total_steps >= args.total_env_steps):          # main.py:283-289
+            if total_steps > args.start_training_steps:
+                save_dir = os.path.join(args.save_model_dir, test_name, f"step_{total_steps}")
+                print(f"Saving model to {save_dir}")
+                save_checkpoint(learner, runner, save_dir, episode, total_steps)
+
+    if hasattr(env, "close") and callable(env.close):
+        env.close()
+    writer.close()
+    print("Training finished.")
+    return {"episodes": episode, "total_steps": total_steps, "log_dir": log_dir, "train_steps": learner.train_step}
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser(description="MA-CJD QMix Training (MI355X hot path)")
+    parser.add_argument("--config", type=str, default="default")
+    parser.add_argument("--env-config", type=str, default="simulation_config")
+    parser.add_argument("--device", type=str, default="cuda")
+    parser.add_argument("--config-dir", type=str, default="config")
+    parser.add_argument("--batch-envs", type=int, default=None)
+    parser.add_argument("--resume", type=str, default=None)
+    a = parser.parse_args(argv)
+    config = load_config(config_name=a.config, config_dir=a.config_dir)
+    config.config, config.env_config, config.device_request = a.config, a.env_config, a.device
+    config.sim_config_path = os.path.join(a.config_dir, f"{a.env_config}.yaml")
+    if a.batch_envs is not None:
+        config.batch_envs = a.batch_envs
+    config.resume = a.resume
+    return run(config)
+
+
+if __name__ == "__main__":
+    main()
