@@ -62,7 +62,9 @@ def test_batched_training_run_checkpoint_resume_eval(tmp_path):
     last = os.path.join(cfg.save_model_dir, cfg.test_name, f"step_{3 * E * 100}")
     assert sorted(os.listdir(last)) == ["agent.pth", "optimizer.pth", "qmix_net.pth", "trainer_state.json"]
     st = json.load(open(os.path.join(last, "trainer_state.json")))
-    assert st["total_steps"] == 3 * E * 100 and st["t_env"] == 300 and st["train_step"] == 300
+    # t_env also counts the greedy evaluation rollout: the reference's runner advances its epsilon clock
+    # in test_mode too (episode_runner.py:119)
+    assert st["total_steps"] == 3 * E * 100 and st["t_env"] == 400 and st["train_step"] == 300
     sd = torch.load(os.path.join(last, "agent.pth"), weights_only=True)
     assert "fc2_q_head.0.weight" in sd and "rnn.weight_hh" in sd
     # resume: continues the counters and the epsilon clock
