@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--sweep", action="store_true", help="also print an E-sweep of the env kernel (stderr)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", dest="no_graphs", action="store_true", help="eager launches (A/B against HIP graphs)")
+    ap.add_argument("--no-gemm-tuning", dest="no_gemm_tuning", action="store_true",
+                    help="library GEMMs with default heuristics (A/B against TunableOp)")
     args = ap.parse_args()
 
     import torch

@@ -38,6 +38,12 @@ def make_step(cli, sc, env, dev, rank, world, mode):
     from .utils.replay_buffer import EpisodeReplayBuffer
 
     args = make_args(sc, cli.hidden, dev, batch_envs=env.batch_envs)
+    gemm_tuning = False
+    if not getattr(cli, "no_gemm_tuning", False):
+        import os
+        import tempfile
+        from . import ops
+        gemm_tuning = ops.enable_gemm_tuning(os.path.join(tempfile.gettempdir(), f"macjd_tunableop_rank{rank}.csv"))
     torch.manual_seed(42)  # identical initial weights on every rank
     with contextlib.redirect_stdout(io.StringIO()):
         mac = BasicMAC(args.obs_shape, args)
@@ -78,6 +84,6 @@ def make_step(cli, sc, env, dev, rank, world, mode):
                 learner.train(buf.sample(args.batch_size), None, sync_stats=False)
 
     extra = {"hidden": cli.hidden, "train_batch_episodes": args.batch_size if mode == "train" else 0,
-             "train_calls_per_step": 1 if mode == "train" else 0, "hip_graphs": bool(use_graphs),
+             "train_calls_per_step": 1 if mode == "train" else 0, "hip_graphs": bool(use_graphs), "gemm_tuning": bool(gemm_tuning),
              "replay_capacity_episodes": args.buffer_size}
     return step_fn, extra

@@ -181,6 +181,9 @@ def run(args):
     print(f"Logs will be saved to: {log_dir}")
 
     sim_config_path = getattr(args, "sim_config_path", None) or os.path.join("config", f"{args.env_config}.yaml")
+    if args.use_cuda and getattr(args, "gemm_tuning", True):
+        from . import ops
+        ops.enable_gemm_tuning(os.path.join(log_dir, "tunableop_results.csv"))
     env, mac, buffer, learner, runner = build_components(args, sim_config_path)
     batch_envs = int(getattr(args, "batch_envs", 1) or 1)
     episodes_per_run = batch_envs

@@ -230,3 +230,22 @@ def mixer_tail(q, w1_raw, b1_raw, wf_raw, v_raw):
     if not q.is_cuda:
         return mixer_tail_reference(q, w1_raw, b1_raw, wf_raw, v_raw)
     return _MixerTailHip.apply(q, w1_raw, b1_raw, wf_raw, v_raw)
+
+
+def enable_gemm_tuning(results_file: Optional[str] = None, max_tuning_ms: int = 30) -> bool:
+    """Let PyTorch's TunableOp pick the rocBLAS / hipBLASLt solution for each library-GEMM shape on this
+    GPU (first call per shape times the candidates).  The path's GEMMs are small and oddly shaped — e.g. the
+    mixer's weight gradients are [192,128] outputs over K = 3168 rows, for which the default heuristic
+    picks a few-workgroup kernel; tuning takes ~10 s once and cut the learner step by 15 % on MI355X.
+    Must run BEFORE any HIP-graph capture.  Returns False when TunableOp is unavailable."""
+    try:
+        import torch.cuda.tunable as tunable
+        tunable.enable(True)
+        tunable.tuning_enable(True)
+        tunable.set_max_tuning_duration(int(max_tuning_ms))
+        if results_file:
+            tunable.set_filename(results_file)
+        return True
+    except Exception as e:  # pragma: no cover
+        print(f"TunableOp unavailable: {e}")
+        return False
