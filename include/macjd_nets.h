@@ -108,6 +108,31 @@ typedef struct macjd_mixer_io {
 int macjd_mixer_tail_forward(const macjd_mixer_io* io, void* hip_stream);
 int macjd_mixer_tail_backward(const macjd_mixer_io* io, void* hip_stream);
 
+/*
+ * Fused chain of up to three dense layers, y = act_n(W_n ... act_1(W_1 x + b_1) ... + b_n), float32 with
+ * exact-f32 MFMA (v_mfma_f32_16x16x4_f32).  Replaces the separate Linear / activation launches of
+ *   RNNAgent.actor            Linear-ReLU-Linear-ReLU-Linear-Sigmoid   (reference core/networks.py:54-61,127)
+ *   fc1 + GRU input transform Linear-ReLU-Linear (W_ih x + b_ih)       (core/networks.py:100, GRUCell)
+ * in the rollout (core/mac.py:168-187) and in the learner's time-parallel unroll (core/qmix.py:241-253).
+ * W_l is torch.nn.Linear's [out, in] row-major weight.  Limits: dims[0] <= 256, hidden widths <= 128, last
+ * width <= 384, one layer's padded weights <= ~120 KB of LDS; MACJD_EUNSUPPORTED otherwise.
+ */
+#define MACJD_ACT_NONE 0
+#define MACJD_ACT_RELU 1
+#define MACJD_ACT_SIGMOID 2
+typedef struct macjd_mlp_io {
+    int64_t n_rows;
+    int32_t n_layers;        /* 1..3 */
+    int32_t dims[4];         /* dims[0] = input width, dims[l+1] = output width of layer l */
+    int32_t act[3];          /* MACJD_ACT_* per layer */
+    const float* W[3];       /* [dims[l+1], dims[l]] contiguous */
+    const float* b[3];       /* [dims[l+1]] */
+    const float* x;  int64_t x_ld;   /* [n_rows, dims[0]], row stride in elements */
+    float* y;        int64_t y_ld;   /* [n_rows, dims[n_layers]] */
+} macjd_mlp_io;
+
+int macjd_mlp_forward(const macjd_mlp_io* io, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

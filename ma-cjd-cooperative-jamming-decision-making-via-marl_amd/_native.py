@@ -23,6 +23,7 @@ EXPORTS = [
     "macjd_scenario_create", "macjd_scenario_destroy", "macjd_scenario_dims",
     "macjd_env_reset", "macjd_env_step", "macjd_env_step_timed",
     "macjd_qhead_select", "macjd_gru_sequence", "macjd_mixer_tail_forward", "macjd_mixer_tail_backward",
+    "macjd_mlp_forward",
 ]
 
 
@@ -90,6 +91,15 @@ class MixerIO(ctypes.Structure):
     ]
 
 
+class MlpIO(ctypes.Structure):
+    """ctypes mirror of ``macjd_mlp_io`` (include/macjd_nets.h)."""
+    _fields_ = [
+        ("n_rows", ctypes.c_int64), ("n_layers", ctypes.c_int32), ("dims", ctypes.c_int32 * 4),
+        ("act", ctypes.c_int32 * 3), ("W", ctypes.c_void_p * 3), ("b", ctypes.c_void_p * 3),
+        ("x", ctypes.c_void_p), ("x_ld", ctypes.c_int64), ("y", ctypes.c_void_p), ("y_ld", ctypes.c_int64),
+    ]
+
+
 _lib: Optional[ctypes.CDLL] = None
 
 
@@ -130,6 +140,8 @@ def load() -> ctypes.CDLL:
     for name in ("macjd_mixer_tail_forward", "macjd_mixer_tail_backward"):
         getattr(lib, name).restype = ctypes.c_int
         getattr(lib, name).argtypes = [ctypes.POINTER(MixerIO), ctypes.c_void_p]
+    lib.macjd_mlp_forward.restype = ctypes.c_int
+    lib.macjd_mlp_forward.argtypes = [ctypes.POINTER(MlpIO), ctypes.c_void_p]
     if lib.macjd_abi_version() != ABI_VERSION:
         raise NativeLibraryError(f"{LIB_NAME}: ABI version {lib.macjd_abi_version()} != expected {ABI_VERSION}")
     _lib = lib

@@ -58,8 +58,22 @@ class RNNAgent(nn.Module):
         """zeros [1, H] on the parameters' device (networks.py:81-86)."""
         return self.fc1.weight.new_zeros(1, self.rnn_hidden_dim)
 
+    def _fused_ok(self, t):
+        """Inference on a HIP device: the fused MFMA chain (ops.mlp_forward) replaces Linear + activation
+        launches.  With autograd on, the stock modules run (the fused kernels have no backward)."""
+        return t.is_cuda and not torch.is_grad_enabled()
+
+    def gru_input_transform(self, agent_inputs):
+        """W_ih ReLU(fc1 obs) + b_ih, [N, 3H]: the time-parallel half of the GRU step (networks.py:100)."""
+        return ops.mlp_forward(agent_inputs, [(self.fc1.weight, self.fc1.bias, ops.ACT_RELU),
+                                              (self.rnn.weight_ih, self.rnn.bias_ih, ops.ACT_NONE)])
+
     def forward(self, agent_inputs, h_in):
         """h' = GRUCell(ReLU(fc1 obs), h)  (networks.py:88-114)."""
+        if self._fused_ok(agent_inputs) and agent_inputs.dim() == 2:
+            gi = self.gru_input_transform(agent_inputs)                       # one fused launch
+            gh = F.linear(h_in.to(gi.device), self.rnn.weight_hh, self.rnn.bias_hh)
+            return torch.ops.aten._thnn_fused_gru_cell(gi, gh, h_in.contiguous())[0]
         x = F.relu(self.fc1(agent_inputs))
         if h_in.device != x.device:
             h_in = h_in.to(x.device)
@@ -67,6 +81,12 @@ class RNNAgent(nn.Module):
 
     def actor_forward(self, inputs):
         """Continuous parameter for EVERY discrete action, [N, A] in (0,1)  (networks.py:116-129)."""
+        if self._fused_ok(inputs):
+            a = self.actor
+            out = ops.mlp_forward(inputs.reshape(-1, inputs.shape[-1]),
+                                  [(a[0].weight, a[0].bias, ops.ACT_RELU), (a[2].weight, a[2].bias, ops.ACT_RELU),
+                                   (a[4].weight, a[4].bias, ops.ACT_SIGMOID)])
+            return out.view(*inputs.shape[:-1], out.shape[-1])
         return self.actor(inputs)
 
     def get_q_value_for_action(self, hidden_state, discrete_action_index, continuous_param, validate=True):

@@ -254,8 +254,7 @@ class QMixLearner:
         gis = []
         for m in macs:
             a = m.agent
-            x = F.relu(a.fc1(rows))                                          # networks.py:100
-            gis.append(F.linear(x, a.rnn.weight_ih, a.rnn.bias_ih).view(B, T, J, 3 * a.rnn_hidden_dim))
+            gis.append(a.gru_input_transform(rows).view(B, T, J, 3 * a.rnn_hidden_dim))  # networks.py:100
         h_alls = ops.gru_sequence_multi(gis, [m.agent.rnn.weight_hh for m in macs],
                                         [m.agent.rnn.bias_hh for m in macs])  # h_0 = 0 (qmix.py:241)
         out = []
@@ -263,7 +262,7 @@ class QMixLearner:
             a = m.agent
             H, A = a.rnn_hidden_dim, a.n_actions
             m.hidden_states = h_all[:, T - 1].reshape(B * J, H) if T > 0 else None
-            params_all = a.actor(rows)                                       # networks.py:127
+            params_all = a.actor_forward(rows)                               # networks.py:127
             l1, l2 = a.fc2_q_head[0], a.fc2_q_head[2]
             base = F.linear(h_all.reshape(B * T * J, H), l1.weight[:, :H], l1.bias)
             out.append(ops.qhead_all_actions(base, params_all, l1.weight, l2.weight, l2.bias, H, A).view(B, T, J, A))

@@ -249,3 +249,58 @@ def enable_gemm_tuning(results_file: Optional[str] = None, max_tuning_ms: int = 
     except Exception as e:  # pragma: no cover
         print(f"TunableOp unavailable: {e}")
         return False
+
+
+# ---------------------------------------------------------------------------------------------
+# Fused dense chain on the matrix cores (csrc/macjd_mlp.hip)
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+_MLP_LDA, _MLP_LDS_FLOATS = 130, 160 * 1024 // 4
+
+
+def mlp_reference(x, layers):
+    """layers = [(weight [out,in], bias [out], act), ...] evaluated with stock torch ops."""
+    for w, b, act in layers:
+        x = F.linear(x, w, b)
+        x = F.relu(x) if act == ACT_RELU else (torch.sigmoid(x) if act == ACT_SIGMOID else x)
+    return x
+
+
+def mlp_supported(dims) -> bool:
+    """Shape limits of macjd_mlp_forward (see include/macjd_nets.h)."""
+    L = len(dims) - 1
+    if not (1 <= L <= 3) or dims[0] > _MLP_LDA - 2 or dims[0] > 256:
+        return False
+    biggest = 0
+    for l in range(L):
+        K, N, last = dims[l], dims[l + 1], l == L - 1
+        if (l > 0 and K > 128) or (not last and N > 128) or (last and N > 384):
+            return False
+        if (N + 15) // 16 not in (1, 2, 3, 4, 8, 12, 24):
+            return False
+        biggest = max(biggest, ((N + 15) // 16) * 16 * (((K + 31) // 32) * 32 + 2))
+    return biggest <= _MLP_LDS_FLOATS - 4 * 16 * _MLP_LDA
+
+
+def mlp_forward(x, layers):
+    """Inference-only fused evaluation of up to three Linear(+activation) layers, [N, in] -> [N, out].
+    HIP device + supported widths: ONE MFMA kernel launch; otherwise stock torch ops (library GEMMs)."""
+    dims = [layers[0][0].shape[1]] + [w.shape[0] for w, _, _ in layers]
+    if not x.is_cuda or not mlp_supported(dims):
+        return mlp_reference(x, layers)
+    lib = _native.load()
+    x = _f32c(x.detach())
+    if x.dim() != 2:
+        x = x.reshape(-1, dims[0])
+    y = torch.empty((x.shape[0], dims[-1]), dtype=torch.float32, device=x.device)
+    io = _native.MlpIO()
+    io.n_rows, io.n_layers = x.shape[0], len(layers)
+    keep = []
+    for l, (w, b, act) in enumerate(layers):
+        w, b = w.detach().float().contiguous(), b.detach().float().contiguous()
+        keep += [w, b]
+        io.dims[l], io.W[l], io.b[l], io.act[l] = dims[l], w.data_ptr(), b.data_ptr(), int(act)
+    io.dims[len(layers)] = dims[-1]
+    io.x, io.x_ld, io.y, io.y_ld = x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0)
+    with torch.cuda.device(x.device):
+        _native.check(lib.macjd_mlp_forward(ctypes.byref(io), _stream(x)), "macjd_mlp_forward")
+    return y

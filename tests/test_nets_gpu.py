@@ -394,3 +394,36 @@ def test_mixer_tail_kernel_forward_backward(J, Em, M):
     with torch.no_grad():  # target mixer path: forward only
         y2 = ops.mixer_tail(*[t.detach() for t in dev_in])
     assert torch.equal(y2, y.detach())
+
+
+@pytest.mark.parametrize("dims,acts,N", [
+    ((46, 128, 128, 9), (1, 1, 2), 12288),     # actor, 3j/4r (weights resident in LDS)
+    ((46, 64, 192), (1, 0), 9600),             # fc1 + GRU input transform, H=64
+    ((24, 128, 384), (1, 0), 130),             # H=128 (24 output tiles, staged per layer)
+    ((184, 128, 128, 33), (1, 1, 2), 1000),    # actor, 12j/16r (staged per layer)
+    ((92, 128, 128, 17), (1, 1, 2), 77),       # actor, 6j/8r
+    ((64, 64), (0,), 63),                      # single layer, ragged row count
+])
+def test_fused_mlp_kernel(dims, acts, N):
+    """Exact-f32 MFMA dense chain vs torch (float64 reference): <= 1e-5 abs on O(1) activations."""
+    from macjd_amd import ops
+    g = torch.Generator().manual_seed(sum(dims) + N)
+    x = torch.randn(N, dims[0], generator=g) * 2.0
+    layers = []
+    for l in range(len(dims) - 1):
+        w = torch.randn(dims[l + 1], dims[l], generator=g) / np.sqrt(dims[l])
+        b = torch.randn(dims[l + 1], generator=g) * 0.3
+        layers.append((w, b, acts[l]))
+    assert ops.mlp_supported(list(dims))
+    ref = ops.mlp_reference(x.double(), [(w.double(), b.double(), a) for w, b, a in layers])
+    with torch.no_grad():
+        y = ops.mlp_forward(x.to(DEV), [(w.to(DEV), b.to(DEV), a) for w, b, a in layers])
+    assert y.shape == (N, dims[-1])
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), atol=1e-5 * max(1.0, float(ref.abs().max())), rtol=1e-5)
+    # strided input rows (a column slice of a wider tensor)
+    xw = torch.randn(N, dims[0] + 5, generator=g).to(DEV)
+    with torch.no_grad():
+        y2 = ops.mlp_forward(xw[:, 2:2 + dims[0]], [(w.to(DEV), b.to(DEV), a) for w, b, a in layers])
+    ref2 = ops.mlp_reference(xw[:, 2:2 + dims[0]].cpu().double(), [(w.double(), b.double(), a) for w, b, a in layers])
+    np.testing.assert_allclose(y2.cpu().numpy(), ref2.numpy(), atol=1e-5 * max(1.0, float(ref2.abs().max())), rtol=1e-5)
+    assert not ops.mlp_supported([300, 64]) and not ops.mlp_supported([46, 256, 9])
