@@ -23,7 +23,7 @@ EXPORTS = [
     "macjd_scenario_create", "macjd_scenario_destroy", "macjd_scenario_dims",
     "macjd_env_reset", "macjd_env_step", "macjd_env_step_timed",
     "macjd_qhead_select", "macjd_gru_sequence", "macjd_mixer_tail_forward", "macjd_mixer_tail_backward",
-    "macjd_mlp_forward",
+    "macjd_mlp_forward", "macjd_mlp_workspace_floats",
 ]
 
 
@@ -141,7 +141,9 @@ def load() -> ctypes.CDLL:
         getattr(lib, name).restype = ctypes.c_int
         getattr(lib, name).argtypes = [ctypes.POINTER(MixerIO), ctypes.c_void_p]
     lib.macjd_mlp_forward.restype = ctypes.c_int
-    lib.macjd_mlp_forward.argtypes = [ctypes.POINTER(MlpIO), ctypes.c_void_p]
+    lib.macjd_mlp_forward.argtypes = [ctypes.POINTER(MlpIO), ctypes.c_void_p, ctypes.c_void_p]
+    lib.macjd_mlp_workspace_floats.restype = ctypes.c_int64
+    lib.macjd_mlp_workspace_floats.argtypes = [ctypes.POINTER(MlpIO)]
     if lib.macjd_abi_version() != ABI_VERSION:
         raise NativeLibraryError(f"{LIB_NAME}: ABI version {lib.macjd_abi_version()} != expected {ABI_VERSION}")
     _lib = lib

@@ -23,6 +23,8 @@ What is different is HOW the hot calls are evaluated:
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -58,6 +60,12 @@ class RNNAgent(nn.Module):
         """zeros [1, H] on the parameters' device (networks.py:81-86)."""
         return self.fc1.weight.new_zeros(1, self.rnn_hidden_dim)
 
+    # Which chains go through the fused MFMA kernel (ops.mlp_forward) on a HIP device under no_grad.  Measured
+    # on MI355X, N = 12 288 rows (scripts/bench_kernels.py, graph replay): actor 46-128-128-9: 24 us fused vs 39 us
+    # as 3 library GEMMs + 3 activation launches; fc1 + GRU input transform 46-64-192: 20 us vs 18 us -> library.
+    fused_actor = os.environ.get("MACJD_FUSED_ACTOR", "1") != "0"
+    fused_gi = os.environ.get("MACJD_FUSED_GI", "0") != "0"
+
     def _fused_ok(self, t):
         """Inference on a HIP device: the fused MFMA chain (ops.mlp_forward) replaces Linear + activation
         launches.  With autograd on, the stock modules run (the fused kernels have no backward)."""
@@ -65,8 +73,10 @@ class RNNAgent(nn.Module):
 
     def gru_input_transform(self, agent_inputs):
         """W_ih ReLU(fc1 obs) + b_ih, [N, 3H]: the time-parallel half of the GRU step (networks.py:100)."""
-        return ops.mlp_forward(agent_inputs, [(self.fc1.weight, self.fc1.bias, ops.ACT_RELU),
-                                              (self.rnn.weight_ih, self.rnn.bias_ih, ops.ACT_NONE)])
+        layers = [(self.fc1.weight, self.fc1.bias, ops.ACT_RELU), (self.rnn.weight_ih, self.rnn.bias_ih, ops.ACT_NONE)]
+        if self.fused_gi and self._fused_ok(agent_inputs):
+            return ops.mlp_forward(agent_inputs, layers)
+        return ops.mlp_reference(agent_inputs, layers)
 
     def forward(self, agent_inputs, h_in):
         """h' = GRUCell(ReLU(fc1 obs), h)  (networks.py:88-114)."""
@@ -81,7 +91,7 @@ class RNNAgent(nn.Module):
 
     def actor_forward(self, inputs):
         """Continuous parameter for EVERY discrete action, [N, A] in (0,1)  (networks.py:116-129)."""
-        if self._fused_ok(inputs):
+        if self.fused_actor and self._fused_ok(inputs):
             a = self.actor
             out = ops.mlp_forward(inputs.reshape(-1, inputs.shape[-1]),
                                   [(a[0].weight, a[0].bias, ops.ACT_RELU), (a[2].weight, a[2].bias, ops.ACT_RELU),

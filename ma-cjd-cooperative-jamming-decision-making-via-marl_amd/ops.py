@@ -254,7 +254,7 @@ def enable_gemm_tuning(results_file: Optional[str] = None, max_tuning_ms: int = 
 # ---------------------------------------------------------------------------------------------
 # Fused dense chain on the matrix cores (csrc/macjd_mlp.hip)
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
-_MLP_LDA, _MLP_LDS_FLOATS = 130, 160 * 1024 // 4
+_MLP_LDS_FLOATS = 160 * 1024 // 4
 
 
 def mlp_reference(x, layers):
@@ -268,7 +268,7 @@ def mlp_reference(x, layers):
 def mlp_supported(dims) -> bool:
     """Shape limits of macjd_mlp_forward (see include/macjd_nets.h)."""
     L = len(dims) - 1
-    if not (1 <= L <= 3) or dims[0] > _MLP_LDA - 2 or dims[0] > 256:
+    if not (1 <= L <= 3) or dims[0] > 256:
         return False
     biggest = 0
     for l in range(L):
@@ -277,8 +277,9 @@ def mlp_supported(dims) -> bool:
             return False
         if (N + 15) // 16 not in (1, 2, 3, 4, 8, 12, 24):
             return False
-        biggest = max(biggest, ((N + 15) // 16) * 16 * (((K + 31) // 32) * 32 + 2))
-    return biggest <= _MLP_LDS_FLOATS - 4 * 16 * _MLP_LDA
+        biggest = max(biggest, ((N + 15) // 16) * ((K + 3) // 4) * 64)
+    lda = ((max(dims[:-1]) + 31) // 32) * 32 + 2
+    return biggest <= _MLP_LDS_FLOATS - 4 * 16 * lda
 
 
 def mlp_forward(x, layers):
@@ -301,6 +302,7 @@ def mlp_forward(x, layers):
         io.dims[l], io.W[l], io.b[l], io.act[l] = dims[l], w.data_ptr(), b.data_ptr(), int(act)
     io.dims[len(layers)] = dims[-1]
     io.x, io.x_ld, io.y, io.y_ld = x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0)
+    ws = torch.empty(int(lib.macjd_mlp_workspace_floats(ctypes.byref(io))), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _native.check(lib.macjd_mlp_forward(ctypes.byref(io), _stream(x)), "macjd_mlp_forward")
+        _native.check(lib.macjd_mlp_forward(ctypes.byref(io), ws.data_ptr(), _stream(x)), "macjd_mlp_forward")
     return y
