@@ -29,6 +29,7 @@ def _cfg(tmp_path, **kw):
     cfg.save_model_dir = str(tmp_path / "models")
     cfg.results_path = str(tmp_path / "logs")
     cfg.log_interval_seconds = 0
+    cfg.gemm_tuning = False   # default library heuristics in tests (TunableOp is process-global)
     cfg.resume = None
     for k, v in kw.items():
         setattr(cfg, k, v)
