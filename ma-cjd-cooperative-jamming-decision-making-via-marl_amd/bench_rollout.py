@@ -50,6 +50,10 @@ def make_step(cli, sc, env, dev, rank, world, mode):
         mac.select_seed = 42 + 1000 * rank
         buf = EpisodeReplayBuffer(args, device=dev)
         learner = QMixLearner(mac, args)
+    if world > 1:  # same seed already gives identical weights; the broadcast makes it independent of that
+        from . import parallel
+        parallel.broadcast_parameters([mac.agent, learner.eval_qmix_net])
+        learner._update_targets()
     runner = BatchedEpisodeRunner(env, mac, buf, args)
     T = args.episode_limit
     np.random.seed(1234 + rank)  # replay sampling stream (np.random.choice, like the reference)

@@ -217,9 +217,10 @@ class QMixLearner:
                         old = snap_o.get(id(p), {}).get(k)
                         v.copy_(old) if old is not None else v.zero_()
         self._graph_a, self._graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph_a):
+        # thread_local: other threads (RCCL's watchdog polls events) may touch the runtime during capture
+        with torch.cuda.graph(self._graph_a, capture_error_mode="thread_local"):
             self._g_out_a = body_a()
-        with torch.cuda.graph(self._graph_b, pool=self._graph_a.pool()):
+        with torch.cuda.graph(self._graph_b, pool=self._graph_a.pool(), capture_error_mode="thread_local"):
             self._g_out_b = self._clip_and_step()
         self._graphs_ready = True
 

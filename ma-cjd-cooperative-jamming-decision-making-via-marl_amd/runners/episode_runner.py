@@ -247,7 +247,8 @@ class BatchedEpisodeRunner:
             self._rollout_body(device_schedule=True)
         torch.cuda.current_stream(dev).wait_stream(s)
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        # thread_local: other threads (RCCL's watchdog polls events) may touch the runtime during capture
+        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
             self._rollout_body(device_schedule=True)
         self.t_env, self._ep = t_env0, ep0
         self.mac.device_schedule = None
