@@ -181,6 +181,21 @@ def main():
                 "traffic_source": pmc_traffic(J, R, E)[1],
                 "kernel": (f"env_step_slots_kernel<{J},{R}>" if E < (1 << 17) else f"env_step_kernel<{J},{R}>"), "us_per_launch": round(ms * 1e3, 3),
                 "bytes_per_env_step": B_step, "envs_per_launch": E}
+    # large-batch point of the same kernel family (2^22 envs): the HBM-bound asymptote, measured every run so the
+    # launch-bound fraction at the benchmark's E is not mistaken for the kernel's streaming rate
+    if rank == 0:
+        Eb = 1 << 22
+        eb = BatchedElectromagneticEnvironment(scenario=sc, batch_envs=Eb, device=dev, seed=1)
+        Tb = torch.randint(0, 2 * R + 1, (J, Eb), generator=g, device=dev, dtype=torch.int32).t()
+        Pb = torch.rand((J, Eb), generator=g, device=dev).t()
+        eb.time_step_kernel(Tb, Pb, iters=3)
+        mb = eb.time_step_kernel(Tb, Pb, iters=20)
+        gb = Eb * B_step / (mb * 1e-3) / 1e9
+        roofline["large_batch"] = {"envs_per_launch": Eb, "us_per_launch": round(mb * 1e3, 2), "achieved": round(gb, 1),
+                                   "frac": round(gb / HBM_PEAK_GBS, 4), "kernel": f"env_step_kernel<{J},{R}>",
+                                   "traffic": pmc_traffic(J, R, Eb)[0]}
+        eb.close()
+        del eb, Tb, Pb
     sweep = None
     if args.sweep and rank == 0:
         sweep = []
