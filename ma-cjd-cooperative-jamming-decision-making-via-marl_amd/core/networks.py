@@ -158,6 +158,10 @@ class QMixer(nn.Module):
         self.V = nn.Sequential(
             nn.Linear(self.state_dim, self.embed_dim), nn.ReLU(),
             nn.Linear(self.embed_dim, 1))
+        # BASELINE.json config 5 ("bf16 mixer MFMA path"): run the hyper-network GEMMs with bf16 inputs and
+        # fp32 accumulation (bf16 MFMA).  Off by default: the reference is fp32 and the 1e-5 tolerance on
+        # Q_tot only holds in fp32; LayerNorm and the clamp / ELU tail stay fp32 either way.
+        self.bf16_hyper = str(getattr(args, "mixer_dtype", "fp32")).lower() in ("bf16", "bfloat16")
 
     def forward(self, agent_qs, states):
         """Q_tot = ELU(q . clamp(W1(s),0,5) + clamp(b1(s),-5,5)) . clamp(Wf(s),0,5) + clamp(V(s),-5,5)
@@ -167,7 +171,13 @@ class QMixer(nn.Module):
         s = self.state_norm(states.reshape(-1, self.state_dim))
         q = agent_qs.reshape(-1, self.n_agents)
         # clamp -> bmm -> ELU -> bmm (+ its backward) is one fused kernel on a HIP device (ops.mixer_tail)
-        y = ops.mixer_tail(q, self.hyper_w_1(s), self.hyper_b_1(s), self.hyper_w_final(s), self.V(s))
+        if self.bf16_hyper and s.is_cuda:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                raw = (self.hyper_w_1(s), self.hyper_b_1(s), self.hyper_w_final(s), self.V(s))
+            raw = tuple(r.float() for r in raw)
+        else:
+            raw = (self.hyper_w_1(s), self.hyper_b_1(s), self.hyper_w_final(s), self.V(s))
+        y = ops.mixer_tail(q, *raw)
         q_tot = y.view(batch_size, -1, 1)
         if q_tot.shape[1] == 1:
             q_tot = q_tot.squeeze(1)
