@@ -10,7 +10,8 @@
  *   macjd_gru_sequence   the learner's `for t in range(max_seq_len)` GRU unroll
  *                        (core/qmix.py:241-253 -> core/networks.py:88-114);
  *   macjd_mixer_tail_*   QMixer.forward after the hyper-network GEMMs, and its backward
- *                        (core/networks.py:283-315).
+ *                        (core/networks.py:283-315);
+ *   macjd_td_loss        TD target + masked MSE + its gradient + logged means (core/qmix.py:155,190-194,212-213).
  * Device pointers, element strides, no torch / HIP types; asynchronous on the given stream.
  */
 #ifndef MACJD_NETS_H
@@ -107,6 +108,28 @@ typedef struct macjd_mixer_io {
 
 int macjd_mixer_tail_forward(const macjd_mixer_io* io, void* hip_stream);
 int macjd_mixer_tail_backward(const macjd_mixer_io* io, void* hip_stream);
+
+/*
+ * TD target + masked mean-squared TD error of QMixLearner.train (reference core/qmix.py:155,190-194):
+ *   target = r + gamma (1 - terminated) tq ;  loss = sum((filled (y - target))^2) / sum(filled)
+ * over M = B * Tm1 (batch, step) pairs, plus dL/dy = 2 filled (y - target) / sum(filled) and the two logged means
+ * (eval_qtot_avg = mean(y), target_qtot_avg = mean(target), qmix.py:212-213).  One single-workgroup launch.
+ * y / tq are contiguous [B*Tm1]; reward / terminated / filled are addressed with (batch, step) element strides so
+ * the [:, :-1] slices of the sampled [B,T,1] tensors need no copy.  terminated / filled are 1-byte bools.
+ */
+typedef struct macjd_tdloss_io {
+    int32_t B, Tm1;
+    float gamma, reserved;
+    const float* y;            /* [B*Tm1] eval Q_tot   */
+    const float* tq;           /* [B*Tm1] target Q_tot */
+    const float* reward;       int64_t r_sb, r_st;
+    const uint8_t* terminated; int64_t t_sb, t_st;
+    const uint8_t* filled;     int64_t f_sb, f_st;
+    float* stats;              /* [4] out: loss, mean(y), mean(target), sum(filled) */
+    float* gy;                 /* [B*Tm1] out: dL/dy */
+} macjd_tdloss_io;
+
+int macjd_td_loss(const macjd_tdloss_io* io, void* hip_stream);
 
 /*
  * Fused chain of up to three dense layers, y = act_n(W_n ... act_1(W_1 x + b_1) ... + b_n), float32 with

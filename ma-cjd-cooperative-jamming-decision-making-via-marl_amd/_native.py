@@ -23,7 +23,7 @@ EXPORTS = [
     "macjd_scenario_create", "macjd_scenario_destroy", "macjd_scenario_dims",
     "macjd_env_reset", "macjd_env_step", "macjd_env_step_timed",
     "macjd_qhead_select", "macjd_gru_sequence", "macjd_mixer_tail_forward", "macjd_mixer_tail_backward",
-    "macjd_mlp_forward", "macjd_mlp_workspace_floats",
+    "macjd_mlp_forward", "macjd_mlp_workspace_floats", "macjd_td_loss",
 ]
 
 
@@ -100,6 +100,18 @@ class MlpIO(ctypes.Structure):
     ]
 
 
+class TdLossIO(ctypes.Structure):
+    """ctypes mirror of ``macjd_tdloss_io`` (include/macjd_nets.h)."""
+    _fields_ = [
+        ("B", ctypes.c_int32), ("Tm1", ctypes.c_int32), ("gamma", ctypes.c_float), ("reserved", ctypes.c_float),
+        ("y", ctypes.c_void_p), ("tq", ctypes.c_void_p),
+        ("reward", ctypes.c_void_p), ("r_sb", ctypes.c_int64), ("r_st", ctypes.c_int64),
+        ("terminated", ctypes.c_void_p), ("t_sb", ctypes.c_int64), ("t_st", ctypes.c_int64),
+        ("filled", ctypes.c_void_p), ("f_sb", ctypes.c_int64), ("f_st", ctypes.c_int64),
+        ("stats", ctypes.c_void_p), ("gy", ctypes.c_void_p),
+    ]
+
+
 _lib: Optional[ctypes.CDLL] = None
 
 
@@ -144,6 +156,8 @@ def load() -> ctypes.CDLL:
     lib.macjd_mlp_forward.argtypes = [ctypes.POINTER(MlpIO), ctypes.c_void_p, ctypes.c_void_p]
     lib.macjd_mlp_workspace_floats.restype = ctypes.c_int64
     lib.macjd_mlp_workspace_floats.argtypes = [ctypes.POINTER(MlpIO)]
+    lib.macjd_td_loss.restype = ctypes.c_int
+    lib.macjd_td_loss.argtypes = [ctypes.POINTER(TdLossIO), ctypes.c_void_p]
     if lib.macjd_abi_version() != ABI_VERSION:
         raise NativeLibraryError(f"{LIB_NAME}: ABI version {lib.macjd_abi_version()} != expected {ABI_VERSION}")
     _lib = lib

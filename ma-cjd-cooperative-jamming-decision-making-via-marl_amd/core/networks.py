@@ -163,6 +163,24 @@ class QMixer(nn.Module):
         # Q_tot only holds in fp32; LayerNorm and the clamp / ELU tail stay fp32 either way.
         self.bf16_hyper = str(getattr(args, "mixer_dtype", "fp32")).lower() in ("bf16", "bfloat16")
 
+    def _hyper_networks(self, s):
+        """(w1_raw [M,J*Em], b1_raw [M,Em], wf_raw [M,Em], v_raw [M,1]) from the normalised state.
+        The four hyper-networks all read the same input, so their FIRST layers run as ONE GEMM over the
+        concatenated weights [Hh + Hh + Em + Em, S] (forward, input-gradient, weight-gradient and bias-gradient
+        each 4 -> 1 launches; the stacked weight-gradient GEMM has 4x the output tile count of the small ones).
+        Same dot products as the four separate nn.Linear calls of the reference (networks.py:283-299)."""
+        Hh, Em = self.hyper_hidden_dim, self.embed_dim
+        w_cat = torch.cat([self.hyper_w_1[0].weight, self.hyper_w_final[0].weight, self.V[0].weight,
+                           self.hyper_b_1.weight], dim=0)
+        b_cat = torch.cat([self.hyper_w_1[0].bias, self.hyper_w_final[0].bias, self.V[0].bias, self.hyper_b_1.bias])
+        out = F.linear(s, w_cat, b_cat)                       # [M, 2 Hh + 2 Em]
+        hid = F.relu(out[:, :2 * Hh + Em])
+        w1_raw = self.hyper_w_1[2](hid[:, :Hh])
+        wf_raw = self.hyper_w_final[2](hid[:, Hh:2 * Hh])
+        v_raw = self.V[2](hid[:, 2 * Hh:])
+        b1_raw = out[:, 2 * Hh + Em:]
+        return w1_raw, b1_raw, wf_raw, v_raw
+
     def forward(self, agent_qs, states):
         """Q_tot = ELU(q . clamp(W1(s),0,5) + clamp(b1(s),-5,5)) . clamp(Wf(s),0,5) + clamp(V(s),-5,5)
         on the LayerNorm-ed state (networks.py:250-315; note clamp, not abs).  Output shape follows
@@ -171,12 +189,10 @@ class QMixer(nn.Module):
         s = self.state_norm(states.reshape(-1, self.state_dim))
         q = agent_qs.reshape(-1, self.n_agents)
         # clamp -> bmm -> ELU -> bmm (+ its backward) is one fused kernel on a HIP device (ops.mixer_tail)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(self.bf16_hyper and s.is_cuda)):
+            raw = self._hyper_networks(s)
         if self.bf16_hyper and s.is_cuda:
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                raw = (self.hyper_w_1(s), self.hyper_b_1(s), self.hyper_w_final(s), self.V(s))
             raw = tuple(r.float() for r in raw)
-        else:
-            raw = (self.hyper_w_1(s), self.hyper_b_1(s), self.hyper_w_final(s), self.V(s))
         y = ops.mixer_tail(q, *raw)
         q_tot = y.view(batch_size, -1, 1)
         if q_tot.shape[1] == 1:

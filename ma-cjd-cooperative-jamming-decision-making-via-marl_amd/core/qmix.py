@@ -68,28 +68,40 @@ class QMixLearner:
         self.optimizer = optim.Adam(params=self.params, lr=args.lr, capturable=(self.device.type == "cuda"))
         self.last_target_update_step = 0
         self.train_step = 0
-        self._flat_grad = None
-        self._flat_params = None
+        self._flat_grad = None   # flat all-reduce buffer, only materialised when world_size > 1
 
     # ------------------------------------------------------------------ distributed gradients
     def _trainable(self):
         """Parameters the loss can reach: the Q-head and the mixer (see module docstring)."""
         return list(self.mac.agent.fc2_q_head.parameters()) + self.qmix_params
 
-    def _bind_flat_grads(self):
-        """Make every trainable ``.grad`` a view into one flat buffer (a single all-reduce, no packing)."""
+    @staticmethod
+    def _world_size():
+        import torch.distributed as dist
+        return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+    def grad_vector(self):
+        """Current gradients of the trainable parameters as one flat vector (a copy unless already flat)."""
+        if self._flat_grad is not None:
+            return self._flat_grad
+        return torch.cat([p.grad.reshape(-1) for p in self._trainable()])
+
+    def _flatten_grads(self):
+        """world_size > 1 only: ONE cat packs the freshly computed gradients into the flat all-reduce buffer and
+        every ``.grad`` becomes a view of it (clip + Adam then read the reduced values).  With a single rank the
+        gradients stay where autograd put them — no packing, no accumulate-into-buffer adds, no memset."""
         tr = self._trainable()
-        n = sum(p.numel() for p in tr)
-        flat = torch.zeros(n, dtype=tr[0].dtype, device=tr[0].device)
+        if self._flat_grad is None:
+            self._flat_grad = torch.empty(sum(p.numel() for p in tr), dtype=tr[0].dtype, device=tr[0].device)
+        torch.cat([p.grad.reshape(-1) for p in tr], out=self._flat_grad)
         off = 0
         for p in tr:
-            p.grad = flat[off:off + p.numel()].view_as(p)
+            p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
             off += p.numel()
-        self._flat_grad, self._flat_params = flat, tr
 
     def _allreduce_grads(self):
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        if self._world_size() <= 1:
             return
         dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
         self._flat_grad.div_(dist.get_world_size())
@@ -105,7 +117,7 @@ class QMixLearner:
         actions_continuous = _to(batch["actions_continuous"], torch.float32, dev)[:, :T]
         rewards = _to(batch["reward"], torch.float32, dev)[:, :T]
         terminated = _to(batch["terminated"], torch.bool, dev)[:, :T]
-        mask = _to(batch["filled"], torch.float32, dev).squeeze(-1)[:, :T]
+        filled = _to(batch["filled"], torch.bool, dev)[:, :T]
         hidden_states = _to(batch["hidden_state"], torch.float32, dev)[:, :T + 1]
         B = states.shape[0]
 
@@ -120,7 +132,6 @@ class QMixLearner:
             next_actions = eval_q_all[:, 1:].argmax(dim=3, keepdim=True)            # qmix.py:138-143 (no mask)
             target_q_taken = torch.gather(target_q_all[:, 1:], 3, next_actions).squeeze(3)  # qmix.py:147
             target_q_mixer = self.target_qmix_net(target_q_taken, states[:, 1:])    # qmix.py:151
-            targets = rewards[:, :-1] + self.args.gamma * (1 - terminated[:, :-1].float()) * target_q_mixer  # :155
 
         # ---- Q(s_t, a_t) from buffered hidden states / actions, qmix.py:161-184 ----
         if T <= 1:
@@ -133,18 +144,17 @@ class QMixLearner:
                 actions_continuous[:, :T - 1].reshape(n_eff, 1), validate=validate_actions).view(B, T - 1, self.n_agents)
         eval_q_mixer = self.eval_qmix_net(q_taken, states[:, :-1])                  # qmix.py:187
 
-        td_error = eval_q_mixer - targets.detach()                                   # qmix.py:190-194
-        m = mask[:, :-1]
-        loss = ((td_error * m.unsqueeze(-1)) ** 2).sum() / m.sum()
+        # targets = r + gamma (1 - terminated) Q_tot'(s', a')            qmix.py:155
+        # loss = sum((filled (Q_tot - targets))^2) / sum(filled)          qmix.py:190-194   (one fused launch)
+        loss, eval_mean, target_mean = ops.td_loss(eval_q_mixer, target_q_mixer, rewards[:, :-1], terminated[:, :-1],
+                                                   filled[:, :-1], self.args.gamma)
 
-        if self._flat_grad is None or self._flat_grad.device != self._trainable()[0].device:
-            self._bind_flat_grads()
-            for p in self.params:  # parameters the graph never reaches keep grad None, as in the reference
-                if not any(p is q for q in self._flat_params):
-                    p.grad = None
-        self._flat_grad.zero_()
+        for p in self.params:   # autograd then ASSIGNS fresh gradients (no accumulate-add kernels, no memset);
+            p.grad = None       # parameters the graph never reaches keep grad None, as in the reference
         loss.backward()
-        return loss.detach(), eval_q_mixer.detach().mean(), targets.mean()
+        if self._world_size() > 1:
+            self._flatten_grads()
+        return loss.detach(), eval_mean.detach(), target_mean.detach()
 
     def _clip_and_step(self):
         grad_norm = torch.nn.utils.clip_grad_norm_(self.params, self.args.grad_norm_clip)  # qmix.py:199

@@ -306,3 +306,52 @@ def mlp_forward(x, layers):
     with torch.cuda.device(x.device):
         _native.check(lib.macjd_mlp_forward(ctypes.byref(io), ws.data_ptr(), _stream(x)), "macjd_mlp_forward")
     return y
+
+
+# ---------------------------------------------------------------------------------------------
+# TD target + masked loss (reference core/qmix.py:155,190-194)
+def td_loss_reference(y, tq, reward, terminated, filled, gamma):
+    """Stock-torch form.  y, tq [B,Tm1,1]; reward / terminated / filled [B,Tm1,1] (views are fine).
+    Returns (loss, mean(y), mean(target))."""
+    targets = reward + gamma * (1 - terminated.float()) * tq
+    m = filled.float()
+    td = (y - targets.detach()) * m
+    return (td ** 2).sum() / m.sum(), y.detach().mean(), targets.mean()
+
+
+class _TdLossHip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, tq, reward, terminated, filled, gamma):
+        lib = _native.load()
+        B, Tm1 = y.shape[0], y.shape[1]
+        yc, tqc = y.detach().float().contiguous(), tq.detach().float().contiguous()
+        stats = torch.empty(4, dtype=torch.float32, device=y.device)
+        gy = torch.empty(B * Tm1, dtype=torch.float32, device=y.device)
+        io = _native.TdLossIO()
+        io.B, io.Tm1, io.gamma = B, Tm1, float(gamma)
+        io.y, io.tq = yc.data_ptr(), tqc.data_ptr()
+        io.reward, io.r_sb, io.r_st = reward.data_ptr(), reward.stride(0), reward.stride(1)
+        io.terminated, io.t_sb, io.t_st = terminated.data_ptr(), terminated.stride(0), terminated.stride(1)
+        io.filled, io.f_sb, io.f_st = filled.data_ptr(), filled.stride(0), filled.stride(1)
+        io.stats, io.gy = stats.data_ptr(), gy.data_ptr()
+        with torch.cuda.device(y.device):
+            _native.check(lib.macjd_td_loss(ctypes.byref(io), _stream(y)), "macjd_td_loss")
+        ctx.save_for_backward(gy)
+        ctx.shape = y.shape
+        ctx.mark_non_differentiable(stats)
+        return stats[0], stats
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_stats):
+        (gy,) = ctx.saved_tensors
+        return (gy * g_loss).view(ctx.shape), None, None, None, None, None
+
+
+def td_loss(y, tq, reward, terminated, filled, gamma):
+    """(loss, mean(y), mean(target)) with loss differentiable in y.  One fused launch on a HIP device."""
+    ok = (y.is_cuda and reward.dtype == torch.float32 and terminated.dtype == torch.bool and filled.dtype == torch.bool
+          and y.shape[1] > 0)
+    if not ok:
+        return td_loss_reference(y, tq, reward, terminated, filled, gamma)
+    loss, stats = _TdLossHip.apply(y, tq, reward, terminated, filled, gamma)
+    return loss, stats[1], stats[2]

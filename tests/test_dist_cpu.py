@@ -60,7 +60,9 @@ def _worker(rank, world, port, out_dir):
     gathered = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
     assert torch.equal(gathered[0], gathered[1]), "ranks diverged after all-reduced steps"
-    np.save(os.path.join(out_dir, f"grad_rank{rank}.npy"), learner._flat_grad.numpy())
+    assert learner._flat_grad is not None          # world_size 2: the flat all-reduce buffer is in use
+    assert all(p.grad.data_ptr() >= learner._flat_grad.data_ptr() for p in learner._trainable())
+    np.save(os.path.join(out_dir, f"grad_rank{rank}.npy"), learner.grad_vector().numpy())
     np.save(os.path.join(out_dir, f"w_rank{rank}.npy"), flat.numpy())
     dist.destroy_process_group()
 
@@ -90,6 +92,7 @@ def test_two_rank_gradient_allreduce(tmp_path):
                  for k in parts[0]}
         learner.train(batch, {})
     # (after clipping both took the same Adam step, so the last-step gradients agree as well)
-    np.testing.assert_allclose(learner._flat_grad.numpy(), g0, rtol=2e-4, atol=1e-6)
+    assert learner._flat_grad is None              # single process: gradients stay where autograd put them
+    np.testing.assert_allclose(learner.grad_vector().numpy(), g0, rtol=2e-4, atol=1e-6)
     flat = torch.cat([p.detach().reshape(-1) for p in learner._trainable()]).numpy()
     np.testing.assert_allclose(flat, np.load(tmp_path / "w_rank0.npy"), rtol=0, atol=2e-6)

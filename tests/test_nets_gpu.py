@@ -476,3 +476,29 @@ def test_other_baseline_configs_end_to_end(scenario, E, H, mixer_dtype):
     # eager update on the same state agrees with the graphed path in kind (finite, same magnitude)
     st = learner.train(buf.sample(32), {})
     assert np.isfinite(st["loss"]) and 0.1 < st["loss"] / max(losses[-1], 1e-9) < 10
+
+
+@pytest.mark.parametrize("B,T", [(32, 100), (4, 12), (3, 2)])
+def test_td_loss_kernel(B, T):
+    """Fused TD target + masked MSE (+ gradient, logged means) vs the stock-torch form, on the [:, :-1] slices
+    of [B,T,1] tensors exactly as the learner passes them (no copies), with ragged `filled` / `terminated`."""
+    from macjd_amd import ops
+    g = torch.Generator().manual_seed(B * T)
+    y = torch.randn(B, T - 1, 1, generator=g)
+    tq = torch.randn(B, T - 1, 1, generator=g)
+    reward = torch.randn(B, T, 1, generator=g)
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    lens[0] = T
+    steps = torch.arange(T).view(1, T, 1)
+    filled = steps < lens.view(B, 1, 1)
+    terminated = steps >= (lens.view(B, 1, 1) - 1)
+    yr = y.clone().double().requires_grad_(True)
+    loss_r, ev_r, tg_r = ops.td_loss_reference(yr, tq.double(), reward.double()[:, :-1], terminated[:, :-1], filled[:, :-1], 0.99)
+    loss_r.backward()
+    yd = y.clone().to(DEV).requires_grad_(True)
+    loss, ev, tg = ops.td_loss(yd, tq.to(DEV), reward.to(DEV)[:, :-1], terminated.to(DEV)[:, :-1], filled.to(DEV)[:, :-1], 0.99)
+    (loss * 1.0).backward()
+    assert loss.item() == pytest.approx(loss_r.item(), rel=1e-5)
+    assert ev.item() == pytest.approx(ev_r.item(), rel=1e-5, abs=1e-6)
+    assert tg.item() == pytest.approx(tg_r.item(), rel=1e-5, abs=1e-6)
+    np.testing.assert_allclose(yd.grad.cpu().numpy(), yr.grad.numpy(), rtol=1e-5, atol=1e-7)
