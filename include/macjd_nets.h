@@ -132,6 +132,38 @@ typedef struct macjd_tdloss_io {
 int macjd_td_loss(const macjd_tdloss_io* io, void* hip_stream);
 
 /*
+ * Gradient clipping + Adam over ONE flat parameter vector (reference core/qmix.py:199-200:
+ * torch.nn.utils.clip_grad_norm_(params, max_norm) followed by torch.optim.Adam.step()):
+ *   total_norm = ||grad||_2 ; coef = min(1, max_norm / (total_norm + 1e-6)) ; g = coef * grad
+ *   step += 1 ; m = m + (1 - b1)(g - m) ; v = b2 v + (1 - b2) g g
+ *   param -= (lr / (1 - b1^step)) * m / (sqrt(v) / sqrt(1 - b2^step) + eps)
+ * param / grad / exp_avg / exp_avg_sq are contiguous float32 [n]; step is a float32 device scalar (torch's
+ * capturable Adam keeps it on the device), read-modify-written by the kernel; grad_norm (out) = total_norm.
+ * `partials` is caller-provided scratch of >= 256 floats.  Two launches.
+ */
+typedef struct macjd_adam_io {
+    int64_t n;
+    float lr, beta1, beta2, eps, max_norm, reserved;
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+    float* step; float* grad_norm; float* partials;
+} macjd_adam_io;
+
+int macjd_clip_adam_step(const macjd_adam_io* io, void* hip_stream);
+
+/*
+ * Gather `n_rows` whole rows (episodes) of up to 8 tensors in ONE launch: dst_k[i, :] = src_k[idx[i], :] as raw
+ * bytes (row_bytes[k] each, multiples of 4).  Replaces the per-key index_select of
+ * EpisodeReplayBuffer.sample (reference utils/replay_buffer.py:181-183).
+ */
+typedef struct macjd_gather_io {
+    int32_t n_tensors, n_rows;
+    const int64_t* idx;            /* [n_rows] device */
+    const void* src[8]; void* dst[8]; int64_t row_bytes[8];
+} macjd_gather_io;
+
+int macjd_gather_rows(const macjd_gather_io* io, void* hip_stream);
+
+/*
  * Fused chain of up to three dense layers, y = act_n(W_n ... act_1(W_1 x + b_1) ... + b_n), float32 with
  * exact-f32 MFMA (v_mfma_f32_16x16x4_f32).  Replaces the separate Linear / activation launches of
  *   RNNAgent.actor            Linear-ReLU-Linear-ReLU-Linear-Sigmoid   (reference core/networks.py:54-61,127)

@@ -23,7 +23,7 @@ EXPORTS = [
     "macjd_scenario_create", "macjd_scenario_destroy", "macjd_scenario_dims",
     "macjd_env_reset", "macjd_env_step", "macjd_env_step_timed",
     "macjd_qhead_select", "macjd_gru_sequence", "macjd_mixer_tail_forward", "macjd_mixer_tail_backward",
-    "macjd_mlp_forward", "macjd_mlp_workspace_floats", "macjd_td_loss",
+    "macjd_mlp_forward", "macjd_mlp_workspace_floats", "macjd_td_loss", "macjd_clip_adam_step", "macjd_gather_rows",
 ]
 
 
@@ -112,6 +112,25 @@ class TdLossIO(ctypes.Structure):
     ]
 
 
+class AdamIO(ctypes.Structure):
+    """ctypes mirror of ``macjd_adam_io`` (include/macjd_nets.h)."""
+    _fields_ = [
+        ("n", ctypes.c_int64), ("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float),
+        ("eps", ctypes.c_float), ("max_norm", ctypes.c_float), ("reserved", ctypes.c_float),
+        ("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p),
+        ("exp_avg_sq", ctypes.c_void_p), ("step", ctypes.c_void_p), ("grad_norm", ctypes.c_void_p),
+        ("partials", ctypes.c_void_p),
+    ]
+
+
+class GatherIO(ctypes.Structure):
+    """ctypes mirror of ``macjd_gather_io`` (include/macjd_nets.h)."""
+    _fields_ = [
+        ("n_tensors", ctypes.c_int32), ("n_rows", ctypes.c_int32), ("idx", ctypes.c_void_p),
+        ("src", ctypes.c_void_p * 8), ("dst", ctypes.c_void_p * 8), ("row_bytes", ctypes.c_int64 * 8),
+    ]
+
+
 _lib: Optional[ctypes.CDLL] = None
 
 
@@ -158,6 +177,10 @@ def load() -> ctypes.CDLL:
     lib.macjd_mlp_workspace_floats.argtypes = [ctypes.POINTER(MlpIO)]
     lib.macjd_td_loss.restype = ctypes.c_int
     lib.macjd_td_loss.argtypes = [ctypes.POINTER(TdLossIO), ctypes.c_void_p]
+    lib.macjd_clip_adam_step.restype = ctypes.c_int
+    lib.macjd_clip_adam_step.argtypes = [ctypes.POINTER(AdamIO), ctypes.c_void_p]
+    lib.macjd_gather_rows.restype = ctypes.c_int
+    lib.macjd_gather_rows.argtypes = [ctypes.POINTER(GatherIO), ctypes.c_void_p]
     if lib.macjd_abi_version() != ABI_VERSION:
         raise NativeLibraryError(f"{LIB_NAME}: ABI version {lib.macjd_abi_version()} != expected {ABI_VERSION}")
     _lib = lib

@@ -65,10 +65,13 @@ class QMixLearner:
         self.qmix_params = list(self.eval_qmix_net.parameters())
         self.params = self.agent_params + self.qmix_params
         # capturable: the step counter lives on the device, so the update can sit inside a HIP graph
-        self.optimizer = optim.Adam(params=self.params, lr=args.lr, capturable=(self.device.type == "cuda"))
+        self.optimizer = optim.Adam(params=self.params, lr=args.lr, capturable=(self.device.type == "cuda"))  # (HIP: the fused step below is used instead)
         self.last_target_update_step = 0
         self.train_step = 0
-        self._flat_grad = None   # flat all-reduce buffer, only materialised when world_size > 1
+        self._flat_grad = None   # flat gradient vector (all-reduce buffer / input of the fused optimiser step)
+        self._flat_param = None
+        if self.device.type == "cuda":
+            self._flatten_trainable()
 
     # ------------------------------------------------------------------ distributed gradients
     def _trainable(self):
@@ -79,6 +82,45 @@ class QMixLearner:
     def _world_size():
         import torch.distributed as dist
         return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+    def _flatten_trainable(self):
+        """HIP device: make the trainable parameters (Q-head + mixer) views of ONE flat vector, with flat Adam
+        moments, so clipping + Adam is a fused two-kernel step (ops.clip_adam_step) instead of ~20 foreach
+        launches.  ``torch.optim.Adam`` keeps owning the state in its usual layout (per-parameter ``step`` /
+        ``exp_avg`` / ``exp_avg_sq`` entries, here views of the flat vectors), so ``optimizer.pth`` and
+        ``load_state_dict`` keep the reference's format (qmix.py:300-315)."""
+        tr = self._trainable()
+        flat = torch.cat([p.detach().reshape(-1) for p in tr])
+        self._flat_param = flat
+        self._flat_exp_avg = torch.zeros_like(flat)
+        self._flat_exp_avg_sq = torch.zeros_like(flat)
+        self._adam_step = torch.zeros((), dtype=torch.float32, device=flat.device)
+        self._grad_norm = torch.zeros((), dtype=torch.float32, device=flat.device)
+        self._adam_partials = torch.zeros(256, dtype=torch.float32, device=flat.device)
+        off = 0
+        for p in tr:
+            n = p.numel()
+            p.data = flat[off:off + n].view_as(p)
+            self.optimizer.state[p] = {"step": self._adam_step, "exp_avg": self._flat_exp_avg[off:off + n].view_as(p),
+                                       "exp_avg_sq": self._flat_exp_avg_sq[off:off + n].view_as(p)}
+            off += n
+
+    def load_optimizer_state(self, state_dict):
+        """``optimizer.load_state_dict`` + re-binding of the loaded moments into the flat vectors."""
+        self.optimizer.load_state_dict(state_dict)
+        if self._flat_param is None:
+            return
+        off = 0
+        for p in self._trainable():
+            n = p.numel()
+            st = self.optimizer.state.get(p, {})
+            if "exp_avg" in st:
+                self._flat_exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                self._flat_exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                self._adam_step.copy_(torch.as_tensor(st["step"], dtype=torch.float32).reshape(()))
+            self.optimizer.state[p] = {"step": self._adam_step, "exp_avg": self._flat_exp_avg[off:off + n].view_as(p),
+                                       "exp_avg_sq": self._flat_exp_avg_sq[off:off + n].view_as(p)}
+            off += n
 
     def grad_vector(self):
         """Current gradients of the trainable parameters as one flat vector (a copy unless already flat)."""
@@ -152,11 +194,17 @@ class QMixLearner:
         for p in self.params:   # autograd then ASSIGNS fresh gradients (no accumulate-add kernels, no memset);
             p.grad = None       # parameters the graph never reaches keep grad None, as in the reference
         loss.backward()
-        if self._world_size() > 1:
-            self._flatten_grads()
+        if self._world_size() > 1 or self._flat_param is not None:
+            self._flatten_grads()   # one cat: the all-reduce buffer and the fused optimiser's input
         return loss.detach(), eval_mean.detach(), target_mean.detach()
 
     def _clip_and_step(self):
+        if self._flat_param is not None:   # HIP device: fused clip_grad_norm_ + Adam on the flat vectors
+            g = self.optimizer.param_groups[0]
+            ops.clip_adam_step(self._flat_param, self._flat_grad, self._flat_exp_avg, self._flat_exp_avg_sq,
+                               self._adam_step, self._grad_norm, self._adam_partials, g["lr"], g["betas"], g["eps"],
+                               self.args.grad_norm_clip)
+            return self._grad_norm
         grad_norm = torch.nn.utils.clip_grad_norm_(self.params, self.args.grad_norm_clip)  # qmix.py:199
         self.optimizer.step()
         return grad_norm.detach() if torch.is_tensor(grad_norm) else torch.as_tensor(grad_norm)
@@ -200,9 +248,18 @@ class QMixLearner:
         if buffer.current_size < 1:
             raise RuntimeError("enable_graphs: the replay buffer is empty")
 
+        keys = [k for k in buffer.buffers if k != "avail_actions"]   # the update never reads the mask (qmix.py:141-142)
+        srcs = [buffer.buffers[k] for k in keys]
+        fused_gather = ops.gather_rows_supported(srcs)
+        stage = {k: torch.empty((self._g_B,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+                 for k, v in zip(keys, srcs)} if fused_gather else None
+
         def body_a():
-            b = {k: v.index_select(0, self._g_idx) for k, v in buffer.buffers.items()
-                 if k != "avail_actions"}  # the update never reads the mask (qmix.py:141-142 is commented out)
+            if fused_gather:   # all keys' episodes in ONE launch into persistent staging tensors
+                ops.gather_rows(self._g_idx, srcs, [stage[k] for k in keys])
+                b = stage
+            else:
+                b = {k: v.index_select(0, self._g_idx) for k, v in zip(keys, srcs)}
             return self._forward_backward(b, self._g_T, validate_actions=False)
 
         # Eager warm-up on a side stream: allocates the optimiser state BEFORE capture (state created during

@@ -469,3 +469,106 @@ extern "C" int macjd_td_loss(const macjd_tdloss_io* io, void* hip_stream) {
     if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
     return MACJD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Gradient clipping + Adam on one flat vector: (1) per-block partial sums of g^2, (2) every block re-reduces the
+// <= 256 partials (deterministic order), derives the clip coefficient and the bias corrections, and updates its
+// slice.  Replaces ~20 foreach / scalar launches of clip_grad_norm_ + capturable Adam.
+namespace macjd {
+
+constexpr int ADAM_BLOCKS = 256;
+
+__global__ void __launch_bounds__(256) adam_sqnorm_kernel(const macjd_adam_io io) {
+    __shared__ float smem[4];
+    float s = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < io.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float g = io.grad[i];
+        s = fmaf(g, g, s);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) io.partials[blockIdx.x] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+}
+
+__global__ void __launch_bounds__(256) adam_update_kernel(const macjd_adam_io io, const int n_partials) {
+    __shared__ float s_tot;
+    if (threadIdx.x < 64) {
+        float s = 0.0f;
+        for (int i = threadIdx.x; i < n_partials; i += 64) s += io.partials[i];
+        s = wave_sum(s);
+        if (threadIdx.x == 0) s_tot = s;
+    }
+    __syncthreads();
+    const float total_norm = sqrtf(s_tot);
+    float coef = io.max_norm / (total_norm + 1e-6f);
+    coef = coef < 1.0f ? coef : 1.0f;
+    const float step = io.step[0] + 1.0f;
+    const float bc1 = 1.0f - powf(io.beta1, step);
+    const float bc2 = 1.0f - powf(io.beta2, step);
+    const float step_size = io.lr / bc1;
+    const float bc2_sqrt = sqrtf(bc2);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < io.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float g = io.grad[i] * coef;
+        float m = io.exp_avg[i], v = io.exp_avg_sq[i];
+        m = m + (1.0f - io.beta1) * (g - m);
+        v = v * io.beta2 + (1.0f - io.beta2) * g * g;
+        io.exp_avg[i] = m;
+        io.exp_avg_sq[i] = v;
+        const float denom = sqrtf(v) / bc2_sqrt + io.eps;
+        io.param[i] -= step_size * (m / denom);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) io.grad_norm[0] = total_norm;
+    // the step counter is bumped by a trailing single-thread launch (all blocks must have read the old value)
+}
+
+__global__ void adam_bump_step_kernel(float* step) { step[0] += 1.0f; }
+
+__global__ void __launch_bounds__(256) gather_rows_kernel(const macjd_gather_io io) {
+    const int k = blockIdx.y;       // tensor
+    const int row = blockIdx.z;     // output row
+    const int64_t words = io.row_bytes[k] >> 2;
+    const uint32_t* __restrict__ src = (const uint32_t*)((const char*)io.src[k] + io.idx[row] * io.row_bytes[k]);
+    uint32_t* __restrict__ dst = (uint32_t*)((char*)io.dst[k] + (int64_t)row * io.row_bytes[k]);
+    const bool vec = ((io.row_bytes[k] & 15) == 0) && ((((uintptr_t)io.src[k]) & 15) == 0) && ((((uintptr_t)io.dst[k]) & 15) == 0);
+    if (vec) {
+        const int64_t n4 = words >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+            ((uint4*)dst)[i] = ((const uint4*)src)[i];
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (int64_t)gridDim.x * blockDim.x)
+            dst[i] = src[i];
+    }
+}
+
+}  // namespace macjd
+
+extern "C" int macjd_clip_adam_step(const macjd_adam_io* io, void* hip_stream) {
+    using namespace macjd;
+    if (!io || io->n < 1 || !io->param || !io->grad || !io->exp_avg || !io->exp_avg_sq || !io->step || !io->grad_norm ||
+        !io->partials)
+        return set_nets_err(MACJD_EINVAL, "macjd_clip_adam_step: bad argument");
+    hipStream_t s = (hipStream_t)hip_stream;
+    int blocks = (int)((io->n + 255) / 256);
+    if (blocks > ADAM_BLOCKS) blocks = ADAM_BLOCKS;
+    hipLaunchKernelGGL(adam_sqnorm_kernel, dim3(blocks), dim3(256), 0, s, *io);
+    hipLaunchKernelGGL(adam_update_kernel, dim3(blocks), dim3(256), 0, s, *io, blocks);
+    hipLaunchKernelGGL(adam_bump_step_kernel, dim3(1), dim3(1), 0, s, io->step);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
+    return MACJD_OK;
+}
+
+extern "C" int macjd_gather_rows(const macjd_gather_io* io, void* hip_stream) {
+    using namespace macjd;
+    if (!io || io->n_tensors < 1 || io->n_tensors > 8 || io->n_rows < 0 || !io->idx)
+        return set_nets_err(MACJD_EINVAL, "macjd_gather_rows: bad argument");
+    for (int k = 0; k < io->n_tensors; ++k)
+        if (!io->src[k] || !io->dst[k] || io->row_bytes[k] < 4 || (io->row_bytes[k] & 3))
+            return set_nets_err(MACJD_EINVAL, "macjd_gather_rows: bad tensor (row bytes must be a positive multiple of 4)");
+    if (io->n_rows == 0) return MACJD_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(8, io->n_tensors, io->n_rows), dim3(256), 0, (hipStream_t)hip_stream, *io);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
+    return MACJD_OK;
+}

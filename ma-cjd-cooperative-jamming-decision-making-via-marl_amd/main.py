@@ -138,7 +138,7 @@ def load_checkpoint(learner, runner, load_dir):
     learner.load_models(load_dir)
     opt_path = os.path.join(load_dir, "optimizer.pth")
     if os.path.exists(opt_path):
-        learner.optimizer.load_state_dict(torch.load(opt_path, map_location=learner.device, weights_only=True))
+        learner.load_optimizer_state(torch.load(opt_path, map_location=learner.device, weights_only=True))
     state = {"episode": 0, "total_steps": 0}
     st_path = os.path.join(load_dir, "trainer_state.json")
     if os.path.exists(st_path):

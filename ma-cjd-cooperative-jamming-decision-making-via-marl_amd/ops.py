@@ -355,3 +355,34 @@ def td_loss(y, tq, reward, terminated, filled, gamma):
         return td_loss_reference(y, tq, reward, terminated, filled, gamma)
     loss, stats = _TdLossHip.apply(y, tq, reward, terminated, filled, gamma)
     return loss, stats[1], stats[2]
+
+
+# ---------------------------------------------------------------------------------------------
+# Fused clip_grad_norm_ + Adam on flat vectors (reference core/qmix.py:199-200)
+def clip_adam_step(param, grad, exp_avg, exp_avg_sq, step, grad_norm, partials, lr, betas, eps, max_norm):
+    """In-place update of ``param`` / ``exp_avg`` / ``exp_avg_sq`` / ``step`` (all flat float32 on one HIP
+    device); writes the pre-clip gradient norm into ``grad_norm``."""
+    lib = _native.load()
+    io = _native.AdamIO()
+    io.n, io.lr, io.beta1, io.beta2, io.eps, io.max_norm = param.numel(), lr, betas[0], betas[1], eps, max_norm
+    io.param, io.grad, io.exp_avg, io.exp_avg_sq = param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr()
+    io.step, io.grad_norm, io.partials = step.data_ptr(), grad_norm.data_ptr(), partials.data_ptr()
+    with torch.cuda.device(param.device):
+        _native.check(lib.macjd_clip_adam_step(ctypes.byref(io), _stream(param)), "macjd_clip_adam_step")
+
+
+def gather_rows_supported(srcs) -> bool:
+    return len(srcs) <= 8 and all(s.is_cuda and s.is_contiguous() and (s[0].numel() * s.element_size()) % 4 == 0
+                                  for s in srcs)
+
+
+def gather_rows(idx, srcs, dsts):
+    """dst_k[i] = src_k[idx[i]] for up to 8 tensors in one launch (whole rows, raw bytes)."""
+    lib = _native.load()
+    io = _native.GatherIO()
+    io.n_tensors, io.n_rows, io.idx = len(srcs), idx.numel(), idx.data_ptr()
+    for k, (s_, d_) in enumerate(zip(srcs, dsts)):
+        assert d_.is_contiguous() and d_.dtype == s_.dtype and d_.shape[1:] == s_.shape[1:] and d_.shape[0] == idx.numel()
+        io.src[k], io.dst[k], io.row_bytes[k] = s_.data_ptr(), d_.data_ptr(), s_[0].numel() * s_.element_size()
+    with torch.cuda.device(idx.device):
+        _native.check(lib.macjd_gather_rows(ctypes.byref(io), _stream(idx)), "macjd_gather_rows")

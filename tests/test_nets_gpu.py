@@ -502,3 +502,53 @@ def test_td_loss_kernel(B, T):
     assert ev.item() == pytest.approx(ev_r.item(), rel=1e-5, abs=1e-6)
     assert tg.item() == pytest.approx(tg_r.item(), rel=1e-5, abs=1e-6)
     np.testing.assert_allclose(yd.grad.cpu().numpy(), yr.grad.numpy(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("max_norm", [1.0, 1e6])
+def test_fused_clip_adam_vs_torch(max_norm):
+    """Fused clip_grad_norm_ + Adam on a flat vector == torch.nn.utils.clip_grad_norm_ + torch.optim.Adam over
+    the same parameters split into tensors, for several steps (bias corrections, clipping active / inactive)."""
+    from macjd_amd import ops
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 74), (64,), (1, 64), (1,), (192, 128), (46,)]
+    n = sum(int(np.prod(s)) for s in shapes)
+    flat0 = torch.randn(n, generator=g)
+    ref_params = []
+    off = 0
+    for s in shapes:
+        k = int(np.prod(s))
+        ref_params.append(flat0[off:off + k].clone().view(s).double().requires_grad_(True))
+        off += k
+    opt = torch.optim.Adam(ref_params, lr=5e-4)
+    p = flat0.clone().to(DEV)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    step, gn, part = torch.zeros((), device=DEV), torch.zeros((), device=DEV), torch.zeros(256, device=DEV)
+    for it in range(5):
+        grad = torch.randn(n, generator=g) * (3.0 if it % 2 else 0.01)
+        off = 0
+        for rp in ref_params:
+            rp.grad = grad[off:off + rp.numel()].view_as(rp).double().clone()
+            off += rp.numel()
+        total = torch.nn.utils.clip_grad_norm_(ref_params, max_norm)
+        opt.step()
+        ops.clip_adam_step(p, grad.to(DEV), m, v, step, gn, part, 5e-4, (0.9, 0.999), 1e-8, max_norm)
+        assert float(gn) == pytest.approx(float(total), rel=1e-5)
+        assert float(step) == it + 1
+        ref_flat = torch.cat([rp.detach().reshape(-1) for rp in ref_params])
+        np.testing.assert_allclose(p.cpu().numpy(), ref_flat.numpy(), atol=2e-6, rtol=0)
+
+
+def test_fused_gather_rows():
+    from macjd_amd import ops
+    g = torch.Generator().manual_seed(1)
+    srcs = [torch.randn(50, 101, 46, generator=g), torch.randint(0, 9, (50, 100, 3, 1), generator=g, dtype=torch.int32),
+            torch.rand(50, 100, 1, generator=g) > 0.5, torch.randn(50, 101, 3, 64, generator=g),
+            torch.randn(50, 3, generator=g).double()]
+    srcs = [s.to(DEV) for s in srcs]
+    idx = torch.tensor([7, 0, 49, 7, 21], device=DEV)
+    assert ops.gather_rows_supported(srcs)
+    dsts = [torch.empty((5,) + tuple(s.shape[1:]), dtype=s.dtype, device=DEV) for s in srcs]
+    ops.gather_rows(idx, srcs, dsts)
+    for s, d in zip(srcs, dsts):
+        assert torch.equal(d, s.index_select(0, idx))
+    assert not ops.gather_rows_supported([torch.zeros(4, 5, dtype=torch.bool, device=DEV)])   # 5-byte rows
