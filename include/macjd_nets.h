@@ -144,7 +144,7 @@ int macjd_td_loss(const macjd_tdloss_io* io, void* hip_stream);
 typedef struct macjd_adam_io {
     int64_t n;
     float lr, beta1, beta2, eps, max_norm, reserved;
-    float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+    float* param; float* grad /* scaled in place by coef, like clip_grad_norm_ */; float* exp_avg; float* exp_avg_sq;
     float* step; float* grad_norm; float* partials;
 } macjd_adam_io;
 

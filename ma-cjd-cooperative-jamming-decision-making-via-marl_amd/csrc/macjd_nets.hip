@@ -510,6 +510,7 @@ __global__ void __launch_bounds__(256) adam_update_kernel(const macjd_adam_io io
     const float bc2_sqrt = sqrtf(bc2);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < io.n; i += (int64_t)gridDim.x * blockDim.x) {
         const float g = io.grad[i] * coef;
+        io.grad[i] = g;   // clip_grad_norm_ scales the gradients in place: .grad holds the clipped values afterwards
         float m = io.exp_avg[i], v = io.exp_avg_sq[i];
         m = m + (1.0f - io.beta1) * (g - m);
         v = v * io.beta2 + (1.0f - io.beta2) * g * g;

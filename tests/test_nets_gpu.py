@@ -531,8 +531,11 @@ def test_fused_clip_adam_vs_torch(max_norm):
             off += rp.numel()
         total = torch.nn.utils.clip_grad_norm_(ref_params, max_norm)
         opt.step()
-        ops.clip_adam_step(p, grad.to(DEV), m, v, step, gn, part, 5e-4, (0.9, 0.999), 1e-8, max_norm)
+        gd = grad.to(DEV)
+        ops.clip_adam_step(p, gd, m, v, step, gn, part, 5e-4, (0.9, 0.999), 1e-8, max_norm)
         assert float(gn) == pytest.approx(float(total), rel=1e-5)
+        np.testing.assert_allclose(gd.cpu().numpy(), torch.cat([rp.grad.reshape(-1) for rp in ref_params]).numpy(),
+                                   rtol=1e-5, atol=1e-9)   # gradients are left clipped in place
         assert float(step) == it + 1
         ref_flat = torch.cat([rp.detach().reshape(-1) for rp in ref_params])
         np.testing.assert_allclose(p.cpu().numpy(), ref_flat.numpy(), atol=2e-6, rtol=0)
