@@ -114,19 +114,21 @@ int macjd_mixer_tail_backward(const macjd_mixer_io* io, void* hip_stream);
  *   target = r + gamma (1 - terminated) tq ;  loss = sum((filled (y - target))^2) / sum(filled)
  * over M = B * Tm1 (batch, step) pairs, plus dL/dy = 2 filled (y - target) / sum(filled) and the two logged means
  * (eval_qtot_avg = mean(y), target_qtot_avg = mean(target), qmix.py:212-213).  One single-workgroup launch.
- * y / tq are contiguous [B*Tm1]; reward / terminated / filled are addressed with (batch, step) element strides so
- * the [:, :-1] slices of the sampled [B,T,1] tensors need no copy.  terminated / filled are 1-byte bools.
+ * y / tq / reward / terminated / filled are addressed with batch (and step) element strides so that slices of
+ * longer [B,T(+1),1] tensors need no copy; gy may be a full-length row with the unused tail zeroed.  terminated / filled are 1-byte bools.
  */
 typedef struct macjd_tdloss_io {
     int32_t B, Tm1;
     float gamma, reserved;
-    const float* y;            /* [B*Tm1] eval Q_tot   */
-    const float* tq;           /* [B*Tm1] target Q_tot */
+    const float* y;            /* eval Q_tot:   element (b, t) at y[b * y_sb + t],  t < Tm1 */
+    const float* tq;           /* target Q_tot: element (b, t) at tq[b * tq_sb + t]         */
+    int64_t y_sb, tq_sb;       /* batch strides (Tm1 for contiguous [B*Tm1] tensors)        */
+    int64_t gy_sb, gy_cols;    /* gy row pitch and row length: columns Tm1..gy_cols-1 are written as zeros */
     const float* reward;       int64_t r_sb, r_st;
     const uint8_t* terminated; int64_t t_sb, t_st;
     const uint8_t* filled;     int64_t f_sb, f_st;
     float* stats;              /* [4] out: loss, mean(y), mean(target), sum(filled) */
-    float* gy;                 /* [B*Tm1] out: dL/dy */
+    float* gy;                 /* out: dL/dy, element (b, t) at gy[b * gy_sb + t] */
 } macjd_tdloss_io;
 
 int macjd_td_loss(const macjd_tdloss_io* io, void* hip_stream);
@@ -159,6 +161,7 @@ typedef struct macjd_gather_io {
     int32_t n_tensors, n_rows;
     const int64_t* idx;            /* [n_rows] device */
     const void* src[8]; void* dst[8]; int64_t row_bytes[8];
+    int64_t dst_row_bytes[8];      /* destination row pitch (>= row_bytes, multiple of 4); 0 = row_bytes */
 } macjd_gather_io;
 
 int macjd_gather_rows(const macjd_gather_io* io, void* hip_stream);

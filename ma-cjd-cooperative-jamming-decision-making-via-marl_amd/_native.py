@@ -105,6 +105,7 @@ class TdLossIO(ctypes.Structure):
     _fields_ = [
         ("B", ctypes.c_int32), ("Tm1", ctypes.c_int32), ("gamma", ctypes.c_float), ("reserved", ctypes.c_float),
         ("y", ctypes.c_void_p), ("tq", ctypes.c_void_p),
+        ("y_sb", ctypes.c_int64), ("tq_sb", ctypes.c_int64), ("gy_sb", ctypes.c_int64), ("gy_cols", ctypes.c_int64),
         ("reward", ctypes.c_void_p), ("r_sb", ctypes.c_int64), ("r_st", ctypes.c_int64),
         ("terminated", ctypes.c_void_p), ("t_sb", ctypes.c_int64), ("t_st", ctypes.c_int64),
         ("filled", ctypes.c_void_p), ("f_sb", ctypes.c_int64), ("f_st", ctypes.c_int64),
@@ -128,6 +129,7 @@ class GatherIO(ctypes.Structure):
     _fields_ = [
         ("n_tensors", ctypes.c_int32), ("n_rows", ctypes.c_int32), ("idx", ctypes.c_void_p),
         ("src", ctypes.c_void_p * 8), ("dst", ctypes.c_void_p * 8), ("row_bytes", ctypes.c_int64 * 8),
+        ("dst_row_bytes", ctypes.c_int64 * 8),
     ]
 
 

@@ -104,7 +104,7 @@ class RNNAgent(nn.Module):
         is the only path through which the learner's loss reaches the agent (core/qmix.py:161-184).
         Evaluated without building the one-hot / concatenated input: W1[:, H + T] is gathered."""
         n = hidden_state.shape[0]
-        idx = discrete_action_index.long()
+        idx = discrete_action_index
         if idx.dim() > 1 and idx.shape[1] == 1:
             idx = idx.squeeze(1)
         # the bounds check reads the device back (host sync); ``validate=False`` is for trusted indices
@@ -123,7 +123,8 @@ class RNNAgent(nn.Module):
         w_h, w_a, w_p = l1.weight[:, :H], l1.weight[:, H:H + self.n_actions], l1.weight[:, H + self.n_actions]
         # action column as a one-hot GEMM (not an index gather: the gather's backward is a serialised
         # scatter-add over ~10^4 rows into A columns; as a GEMM both directions are dense products)
-        onehot = F.one_hot(idx, num_classes=self.n_actions).to(hidden_state.dtype)
+        onehot = (idx.unsqueeze(1) == torch.arange(self.n_actions, device=idx.device, dtype=idx.dtype)) \
+            .to(hidden_state.dtype)     # == F.one_hot(idx.long(), A).float(): compare + cast, any integer dtype
         pre = F.linear(hidden_state, w_h, l1.bias) + F.linear(onehot, w_a) + continuous_param * w_p.unsqueeze(0)
         return l2(F.relu(pre))
 
@@ -174,11 +175,12 @@ class QMixer(nn.Module):
                            self.hyper_b_1.weight], dim=0)
         b_cat = torch.cat([self.hyper_w_1[0].bias, self.hyper_w_final[0].bias, self.V[0].bias, self.hyper_b_1.bias])
         out = F.linear(s, w_cat, b_cat)                       # [M, 2 Hh + 2 Em]
-        hid = F.relu(out[:, :2 * Hh + Em])
-        w1_raw = self.hyper_w_1[2](hid[:, :Hh])
-        wf_raw = self.hyper_w_final[2](hid[:, Hh:2 * Hh])
-        v_raw = self.V[2](hid[:, 2 * Hh:])
-        b1_raw = out[:, 2 * Hh + Em:]
+        # split (backward = ONE cat of the four gradients) rather than slices (backward = a zero-fill + copy per
+        # slice plus adds to merge them)
+        h_w1, h_wf, h_v, b1_raw = out.split([Hh, Hh, Em, Em], dim=1)
+        w1_raw = self.hyper_w_1[2](F.relu(h_w1))
+        wf_raw = self.hyper_w_final[2](F.relu(h_wf))
+        v_raw = self.V[2](F.relu(h_v))
         return w1_raw, b1_raw, wf_raw, v_raw
 
     def forward(self, agent_qs, states):

@@ -198,6 +198,37 @@ class QMixLearner:
             self._flatten_grads()   # one cat: the all-reduce buffer and the fused optimiser's input
         return loss.detach(), eval_mean.detach(), target_mean.detach()
 
+    def _forward_backward_full(self, st, T):
+        """Same update as ``_forward_backward`` for a batch of FULL-LENGTH episodes held in contiguous staging
+        tensors with T+1 steps on every key (actions padded with a zero row).  Every quantity is evaluated for
+        all T+1 steps and the loss kernel picks the steps it needs through strides, so no slice of a [B,T+1,...]
+        tensor is ever reshaped (= copied) and autograd sees no slicing (no zero-fill + copy in backward).
+        Rows that the reference never evaluates (eval step T-1 and T, target step 0) cost ~2 % extra arithmetic,
+        receive zero gradient and do not enter the loss: the result equals ``_forward_backward`` (tested)."""
+        B, T1 = st["state"].shape[0], T + 1
+        J, H = self.n_agents, self.args.rnn_hidden_dim
+        rollout_hidden = self.mac.hidden_states
+        with torch.no_grad():
+            target_q_all, eval_q_all = self._all_action_q_multi([self.target_mac, self.mac], st["obs"])  # [B,T+1,J,A]
+            self.mac.hidden_states = rollout_hidden
+            next_actions = eval_q_all.argmax(dim=3, keepdim=True)                      # qmix.py:138-143 (no mask)
+            target_q_taken = torch.gather(target_q_all, 3, next_actions).squeeze(3)    # qmix.py:147
+            target_q_tot = self.target_qmix_net(target_q_taken, st["state"])           # [B,T+1,1], qmix.py:151
+        n = B * T1 * J
+        q_taken = self.mac.agent.get_q_value_for_action(
+            st["hidden_state"].view(n, H), st["actions_discrete"].view(n, 1), st["actions_continuous"].view(n, 1),
+            validate=False).view(B, T1, J)                                              # qmix.py:161-184
+        eval_q_tot = self.eval_qmix_net(q_taken, st["state"])                          # [B,T+1,1], qmix.py:187
+        # loss over eval steps 0..T-2 against targets built from target steps 1..T-1 (qmix.py:155,190-194)
+        loss, eval_mean, target_mean = ops.td_loss_full(eval_q_tot, target_q_tot, st["reward"], st["terminated"],
+                                                        st["filled"], self.args.gamma, T - 1, 1)
+        for p in self.params:
+            p.grad = None
+        loss.backward()
+        if self._world_size() > 1 or self._flat_param is not None:
+            self._flatten_grads()
+        return loss.detach(), eval_mean.detach(), target_mean.detach()
+
     def _clip_and_step(self):
         if self._flat_param is not None:   # HIP device: fused clip_grad_norm_ + Adam on the flat vectors
             g = self.optimizer.param_groups[0]
@@ -250,16 +281,19 @@ class QMixLearner:
 
         keys = [k for k in buffer.buffers if k != "avail_actions"]   # the update never reads the mask (qmix.py:141-142)
         srcs = [buffer.buffers[k] for k in keys]
-        fused_gather = ops.gather_rows_supported(srcs)
-        stage = {k: torch.empty((self._g_B,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
-                 for k, v in zip(keys, srcs)} if fused_gather else None
+        fused = ops.gather_rows_supported(srcs) and self._g_T >= 2
+        if fused:
+            # persistent staging tensors, every key with T+1 steps (the action rows get a zero step T) so that the
+            # full-length update never slices; ONE launch gathers all keys' episodes
+            T1 = self._g_T + 1
+            stage = {k: torch.zeros((self._g_B, T1) + tuple(v.shape[2:]), dtype=v.dtype, device=v.device)
+                     for k, v in zip(keys, srcs)}
 
         def body_a():
-            if fused_gather:   # all keys' episodes in ONE launch into persistent staging tensors
+            if fused:
                 ops.gather_rows(self._g_idx, srcs, [stage[k] for k in keys])
-                b = stage
-            else:
-                b = {k: v.index_select(0, self._g_idx) for k, v in zip(keys, srcs)}
+                return self._forward_backward_full(stage, self._g_T)
+            b = {k: v.index_select(0, self._g_idx) for k, v in zip(keys, srcs)}
             return self._forward_backward(b, self._g_T, validate_actions=False)
 
         # Eager warm-up on a side stream: allocates the optimiser state BEFORE capture (state created during

@@ -432,8 +432,8 @@ __global__ void __launch_bounds__(1024) td_loss_kernel(const macjd_tdloss_io io)
         const float r = io.reward[b * io.r_sb + t * io.r_st];
         const float term = io.terminated[b * io.t_sb + t * io.t_st] ? 1.0f : 0.0f;
         const float m = io.filled[b * io.f_sb + t * io.f_st] ? 1.0f : 0.0f;
-        const float y = io.y[i];
-        const float target = r + io.gamma * (1.0f - term) * io.tq[i];   // qmix.py:155
+        const float y = io.y[b * io.y_sb + t];
+        const float target = r + io.gamma * (1.0f - term) * io.tq[b * io.tq_sb + t];   // qmix.py:155
         const float e = (y - target) * m;                                // qmix.py:190-193
         s_m += m; s_e2 += e * e; s_y += y; s_t += target;
     }
@@ -448,12 +448,17 @@ __global__ void __launch_bounds__(1024) td_loss_kernel(const macjd_tdloss_io io)
         io.stats[3] = tot_m;
     }
     const float scale = 2.0f / tot_m;
-    for (int i = threadIdx.x; i < M; i += blockDim.x) {
-        const int b = i / io.Tm1, t = i - b * io.Tm1;
-        const float term = io.terminated[b * io.t_sb + t * io.t_st] ? 1.0f : 0.0f;
-        const float m = io.filled[b * io.f_sb + t * io.f_st] ? 1.0f : 0.0f;
-        const float target = io.reward[b * io.r_sb + t * io.r_st] + io.gamma * (1.0f - term) * io.tq[i];
-        io.gy[i] = scale * m * (io.y[i] - target);
+    const int cols = (int)io.gy_cols;
+    for (int i = threadIdx.x; i < io.B * cols; i += blockDim.x) {
+        const int b = i / cols, t = i - b * cols;
+        float g = 0.0f;   // columns past Tm1 (full-length rows) carry no loss
+        if (t < io.Tm1) {
+            const float term = io.terminated[b * io.t_sb + t * io.t_st] ? 1.0f : 0.0f;
+            const float m = io.filled[b * io.f_sb + t * io.f_st] ? 1.0f : 0.0f;
+            const float target = io.reward[b * io.r_sb + t * io.r_st] + io.gamma * (1.0f - term) * io.tq[b * io.tq_sb + t];
+            g = scale * m * (io.y[b * io.y_sb + t] - target);
+        }
+        io.gy[b * io.gy_sb + t] = g;
     }
 }
 
@@ -464,6 +469,8 @@ extern "C" int macjd_td_loss(const macjd_tdloss_io* io, void* hip_stream) {
     if (!io || io->B < 1 || io->Tm1 < 1) return set_nets_err(MACJD_EINVAL, "macjd_td_loss: bad B / Tm1");
     if (!io->y || !io->tq || !io->reward || !io->terminated || !io->filled || !io->stats || !io->gy)
         return set_nets_err(MACJD_EINVAL, "macjd_td_loss: NULL pointer");
+    if (io->y_sb < io->Tm1 || io->tq_sb < io->Tm1 || io->gy_cols < io->Tm1 || io->gy_sb < io->gy_cols)
+        return set_nets_err(MACJD_EINVAL, "macjd_td_loss: bad strides");
     hipLaunchKernelGGL(td_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, *io);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
@@ -530,8 +537,10 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const macjd_gather_io 
     const int row = blockIdx.z;     // output row
     const int64_t words = io.row_bytes[k] >> 2;
     const uint32_t* __restrict__ src = (const uint32_t*)((const char*)io.src[k] + io.idx[row] * io.row_bytes[k]);
-    uint32_t* __restrict__ dst = (uint32_t*)((char*)io.dst[k] + (int64_t)row * io.row_bytes[k]);
-    const bool vec = ((io.row_bytes[k] & 15) == 0) && ((((uintptr_t)io.src[k]) & 15) == 0) && ((((uintptr_t)io.dst[k]) & 15) == 0);
+    const int64_t dpitch = io.dst_row_bytes[k] ? io.dst_row_bytes[k] : io.row_bytes[k];
+    uint32_t* __restrict__ dst = (uint32_t*)((char*)io.dst[k] + (int64_t)row * dpitch);
+    const bool vec = ((io.row_bytes[k] & 15) == 0) && ((dpitch & 15) == 0) && ((((uintptr_t)io.src[k]) & 15) == 0) &&
+                     ((((uintptr_t)io.dst[k]) & 15) == 0);
     if (vec) {
         const int64_t n4 = words >> 2;
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
@@ -565,7 +574,8 @@ extern "C" int macjd_gather_rows(const macjd_gather_io* io, void* hip_stream) {
     if (!io || io->n_tensors < 1 || io->n_tensors > 8 || io->n_rows < 0 || !io->idx)
         return set_nets_err(MACJD_EINVAL, "macjd_gather_rows: bad argument");
     for (int k = 0; k < io->n_tensors; ++k)
-        if (!io->src[k] || !io->dst[k] || io->row_bytes[k] < 4 || (io->row_bytes[k] & 3))
+        if (!io->src[k] || !io->dst[k] || io->row_bytes[k] < 4 || (io->row_bytes[k] & 3) || (io->dst_row_bytes[k] & 3) ||
+            (io->dst_row_bytes[k] && io->dst_row_bytes[k] < io->row_bytes[k]))
             return set_nets_err(MACJD_EINVAL, "macjd_gather_rows: bad tensor (row bytes must be a positive multiple of 4)");
     if (io->n_rows == 0) return MACJD_OK;
     hipLaunchKernelGGL(gather_rows_kernel, dim3(8, io->n_tensors, io->n_rows), dim3(256), 0, (hipStream_t)hip_stream, *io);

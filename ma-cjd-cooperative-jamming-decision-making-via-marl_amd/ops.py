@@ -320,31 +320,43 @@ def td_loss_reference(y, tq, reward, terminated, filled, gamma):
 
 
 class _TdLossHip(torch.autograd.Function):
+    """y_full [B, Ty, 1] (eval Q_tot, uses steps 0..Tm1-1), tq_full [B, Tq, 1] (target Q_tot, uses steps
+    tq_off..tq_off+Tm1-1); reward / terminated / filled are [B, >=Tm1, 1] views.  No slicing happens in autograd:
+    the gradient comes back as a full-length [B, Ty, 1] tensor whose unused steps are zero."""
+
     @staticmethod
-    def forward(ctx, y, tq, reward, terminated, filled, gamma):
+    def forward(ctx, y_full, tq_full, reward, terminated, filled, gamma, Tm1, tq_off):
         lib = _native.load()
-        B, Tm1 = y.shape[0], y.shape[1]
-        yc, tqc = y.detach().float().contiguous(), tq.detach().float().contiguous()
-        stats = torch.empty(4, dtype=torch.float32, device=y.device)
-        gy = torch.empty(B * Tm1, dtype=torch.float32, device=y.device)
+        B, Ty = y_full.shape[0], y_full.shape[1]
+        yc, tqc = y_full.detach().float().contiguous(), tq_full.detach().float().contiguous()
+        stats = torch.empty(4, dtype=torch.float32, device=yc.device)
+        gy = torch.empty((B, Ty, 1), dtype=torch.float32, device=yc.device)
         io = _native.TdLossIO()
-        io.B, io.Tm1, io.gamma = B, Tm1, float(gamma)
-        io.y, io.tq = yc.data_ptr(), tqc.data_ptr()
+        io.B, io.Tm1, io.gamma = B, int(Tm1), float(gamma)
+        io.y, io.y_sb = yc.data_ptr(), Ty
+        io.tq, io.tq_sb = tqc.data_ptr() + 4 * int(tq_off), tqc.shape[1]
+        io.gy, io.gy_sb, io.gy_cols = gy.data_ptr(), Ty, Ty
         io.reward, io.r_sb, io.r_st = reward.data_ptr(), reward.stride(0), reward.stride(1)
         io.terminated, io.t_sb, io.t_st = terminated.data_ptr(), terminated.stride(0), terminated.stride(1)
         io.filled, io.f_sb, io.f_st = filled.data_ptr(), filled.stride(0), filled.stride(1)
-        io.stats, io.gy = stats.data_ptr(), gy.data_ptr()
-        with torch.cuda.device(y.device):
-            _native.check(lib.macjd_td_loss(ctypes.byref(io), _stream(y)), "macjd_td_loss")
+        io.stats = stats.data_ptr()
+        with torch.cuda.device(yc.device):
+            _native.check(lib.macjd_td_loss(ctypes.byref(io), _stream(yc)), "macjd_td_loss")
         ctx.save_for_backward(gy)
-        ctx.shape = y.shape
         ctx.mark_non_differentiable(stats)
         return stats[0], stats
 
     @staticmethod
     def backward(ctx, g_loss, _g_stats):
         (gy,) = ctx.saved_tensors
-        return (gy * g_loss).view(ctx.shape), None, None, None, None, None
+        return gy * g_loss, None, None, None, None, None, None, None
+
+
+def td_loss_full(y_full, tq_full, reward, terminated, filled, gamma, Tm1, tq_off):
+    """Full-length form used by the graphed update: loss over eval steps 0..Tm1-1 against target steps
+    tq_off..tq_off+Tm1-1, without slicing either tensor (HIP device only)."""
+    loss, stats = _TdLossHip.apply(y_full, tq_full, reward, terminated, filled, gamma, Tm1, tq_off)
+    return loss, stats[1], stats[2]
 
 
 def td_loss(y, tq, reward, terminated, filled, gamma):
@@ -353,7 +365,7 @@ def td_loss(y, tq, reward, terminated, filled, gamma):
           and y.shape[1] > 0)
     if not ok:
         return td_loss_reference(y, tq, reward, terminated, filled, gamma)
-    loss, stats = _TdLossHip.apply(y, tq, reward, terminated, filled, gamma)
+    loss, stats = _TdLossHip.apply(y, tq, reward, terminated, filled, gamma, y.shape[1], 0)
     return loss, stats[1], stats[2]
 
 
@@ -382,7 +394,8 @@ def gather_rows(idx, srcs, dsts):
     io = _native.GatherIO()
     io.n_tensors, io.n_rows, io.idx = len(srcs), idx.numel(), idx.data_ptr()
     for k, (s_, d_) in enumerate(zip(srcs, dsts)):
-        assert d_.is_contiguous() and d_.dtype == s_.dtype and d_.shape[1:] == s_.shape[1:] and d_.shape[0] == idx.numel()
+        assert d_.is_contiguous() and d_.dtype == s_.dtype and d_.shape[0] == idx.numel() and d_[0].numel() >= s_[0].numel()
         io.src[k], io.dst[k], io.row_bytes[k] = s_.data_ptr(), d_.data_ptr(), s_[0].numel() * s_.element_size()
+        io.dst_row_bytes[k] = d_.stride(0) * d_.element_size()   # destination rows may be longer (padded steps)
     with torch.cuda.device(idx.device):
         _native.check(lib.macjd_gather_rows(ctypes.byref(io), _stream(idx)), "macjd_gather_rows")

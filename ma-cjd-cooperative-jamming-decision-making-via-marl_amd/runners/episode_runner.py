@@ -198,7 +198,12 @@ class BatchedEpisodeRunner:
         if self._static and not self._static_filled:
             self._fill_static()
         self._rdpj_sum.zero_()
-        self._obs, self._avail = self.env.get_obs(), self.env.get_avail_actions()
+        if self._static:
+            # the filled staging row is a CONTIGUOUS [E, J, S] copy of the (broadcast) observation: the MAC can
+            # view it as [E*J, S] without materialising 2 MB per step; the mask stays the env's broadcast view
+            self._obs, self._avail = self.stage["obs"][0], self.env.get_avail_actions()
+        else:
+            self._obs, self._avail = self.env.get_obs(), self.env.get_avail_actions()
 
     def step(self, t, test_mode=False):
         """Batched step t of the current episodes: agent forward + MP-DQN Q + epsilon-greedy (one fused
