@@ -286,8 +286,9 @@ class QMixLearner:
             # persistent staging tensors, every key with T+1 steps (the action rows get a zero step T) so that the
             # full-length update never slices; ONE launch gathers all keys' episodes
             T1 = self._g_T + 1
-            stage = {k: torch.zeros((self._g_B, T1) + tuple(v.shape[2:]), dtype=v.dtype, device=v.device)
-                     for k, v in zip(keys, srcs)}
+            padded = ("actions_discrete", "actions_continuous")   # T-step keys that the update reshapes with T+1 rows
+            stage = {k: torch.zeros((self._g_B, T1 if k in padded else v.shape[1]) + tuple(v.shape[2:]), dtype=v.dtype,
+                                    device=v.device) for k, v in zip(keys, srcs)}
 
         def body_a():
             if fused:
