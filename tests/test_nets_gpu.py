@@ -325,10 +325,12 @@ def test_graphed_train_equals_eager_train():
         for k in se:
             assert sg[k] == pytest.approx(se[k], rel=1e-4, abs=1e-6), (step, k)
     assert graphed.train_step == eager.train_step == 7 and graphed.last_target_update_step == 6
+    # weights after 7 Adam steps (lr 5e-4): Adam's m / sqrt(v) amplifies summation-order noise of near-zero gradient
+    # entries (the graphed path reduces over full-length rows), hence 2e-5 rather than float epsilon
     for (k, a), b in zip(mac_e.agent.state_dict().items(), mac_g.agent.state_dict().values()):
-        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-6, rtol=0, err_msg=k)
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-5, rtol=0, err_msg=k)
     for (k, a), b in zip(eager.target_qmix_net.state_dict().items(), graphed.target_qmix_net.state_dict().values()):
-        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-6, rtol=0, err_msg=k)
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-5, rtol=0, err_msg=k)
 
 
 def test_graphed_rollout_equals_eager_rollout():
