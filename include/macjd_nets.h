@@ -153,6 +153,26 @@ typedef struct macjd_adam_io {
 int macjd_clip_adam_step(const macjd_adam_io* io, void* hip_stream);
 
 /*
+ * Weight and bias gradient of y = x W^T + b over K rows:  dW[M,N] = gout[K,M]^T x inp[K,N],  db[M] = sum_k gout[k,:]
+ * (the backward of torch.nn.Linear for its parameters, core/qmix.py:198 loss.backward()).  On this path the outputs
+ * are tiny (e.g. [192,128]) and K is 3e3..1e4 rows, so the reduction is split over K: every workgroup computes one
+ * 64x64 output tile for one 128-row K-chunk on exact-f32 MFMA into `workspace`, a second launch sums the chunks in
+ * fixed order (deterministic).  workspace >= macjd_linear_wgrad_workspace_floats(K, M, N) floats.
+ */
+typedef struct macjd_wgrad_io {
+    int64_t K;
+    int32_t M, N;
+    const float* gout; int64_t gout_ld;   /* [K,M] row stride (elements) */
+    const float* inp;  int64_t inp_ld;    /* [K,N] */
+    float* dW;         int64_t dw_ld;     /* [M,N] out */
+    float* db;                            /* [M] out, optional */
+    float* workspace;
+} macjd_wgrad_io;
+
+int64_t macjd_linear_wgrad_workspace_floats(int64_t K, int32_t M, int32_t N);
+int macjd_linear_wgrad(const macjd_wgrad_io* io, void* hip_stream);
+
+/*
  * Gather `n_rows` whole rows (episodes) of up to 8 tensors in ONE launch: dst_k[i, :] = src_k[idx[i], :] as raw
  * bytes (row_bytes[k] each, multiples of 4).  Replaces the per-key index_select of
  * EpisodeReplayBuffer.sample (reference utils/replay_buffer.py:181-183).

@@ -24,6 +24,7 @@ EXPORTS = [
     "macjd_env_reset", "macjd_env_step", "macjd_env_step_timed",
     "macjd_qhead_select", "macjd_gru_sequence", "macjd_mixer_tail_forward", "macjd_mixer_tail_backward",
     "macjd_mlp_forward", "macjd_mlp_workspace_floats", "macjd_td_loss", "macjd_clip_adam_step", "macjd_gather_rows",
+    "macjd_linear_wgrad", "macjd_linear_wgrad_workspace_floats",
 ]
 
 
@@ -133,6 +134,15 @@ class GatherIO(ctypes.Structure):
     ]
 
 
+class WgradIO(ctypes.Structure):
+    """ctypes mirror of ``macjd_wgrad_io`` (include/macjd_nets.h)."""
+    _fields_ = [
+        ("K", ctypes.c_int64), ("M", ctypes.c_int32), ("N", ctypes.c_int32),
+        ("gout", ctypes.c_void_p), ("gout_ld", ctypes.c_int64), ("inp", ctypes.c_void_p), ("inp_ld", ctypes.c_int64),
+        ("dW", ctypes.c_void_p), ("dw_ld", ctypes.c_int64), ("db", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
+    ]
+
+
 _lib: Optional[ctypes.CDLL] = None
 
 
@@ -183,6 +193,10 @@ def load() -> ctypes.CDLL:
     lib.macjd_clip_adam_step.argtypes = [ctypes.POINTER(AdamIO), ctypes.c_void_p]
     lib.macjd_gather_rows.restype = ctypes.c_int
     lib.macjd_gather_rows.argtypes = [ctypes.POINTER(GatherIO), ctypes.c_void_p]
+    lib.macjd_linear_wgrad.restype = ctypes.c_int
+    lib.macjd_linear_wgrad.argtypes = [ctypes.POINTER(WgradIO), ctypes.c_void_p]
+    lib.macjd_linear_wgrad_workspace_floats.restype = ctypes.c_int64
+    lib.macjd_linear_wgrad_workspace_floats.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
     if lib.macjd_abi_version() != ABI_VERSION:
         raise NativeLibraryError(f"{LIB_NAME}: ABI version {lib.macjd_abi_version()} != expected {ABI_VERSION}")
     _lib = lib

@@ -102,7 +102,7 @@ class RNNAgent(nn.Module):
     def get_q_value_for_action(self, hidden_state, discrete_action_index, continuous_param, validate=True):
         """Q(h, T, P) for one (action, parameter) per row (networks.py:131-180).  Differentiable; this
         is the only path through which the learner's loss reaches the agent (core/qmix.py:161-184).
-        Evaluated without building the one-hot / concatenated input: W1[:, H + T] is gathered."""
+        """
         n = hidden_state.shape[0]
         idx = discrete_action_index
         if idx.dim() > 1 and idx.shape[1] == 1:
@@ -118,15 +118,13 @@ class RNNAgent(nn.Module):
                 continuous_param = continuous_param.view(n, 1)
             except RuntimeError:
                 raise ValueError(f"Unexpected continuous_param shape: {continuous_param.shape}, expected ({n}, 1)")
-        H = self.rnn_hidden_dim
         l1, l2 = self.fc2_q_head[0], self.fc2_q_head[2]
-        w_h, w_a, w_p = l1.weight[:, :H], l1.weight[:, H:H + self.n_actions], l1.weight[:, H + self.n_actions]
-        # action column as a one-hot GEMM (not an index gather: the gather's backward is a serialised
-        # scatter-add over ~10^4 rows into A columns; as a GEMM both directions are dense products)
+        # cat([h, onehot(a), P]) -> Linear -> ReLU -> Linear, exactly the reference's formulation (networks.py:171-176);
+        # the one-hot is a compare + cast (any integer dtype), the Linears use the split-K weight gradient on a HIP device
         onehot = (idx.unsqueeze(1) == torch.arange(self.n_actions, device=idx.device, dtype=idx.dtype)) \
-            .to(hidden_state.dtype)     # == F.one_hot(idx.long(), A).float(): compare + cast, any integer dtype
-        pre = F.linear(hidden_state, w_h, l1.bias) + F.linear(onehot, w_a) + continuous_param * w_p.unsqueeze(0)
-        return l2(F.relu(pre))
+            .to(hidden_state.dtype)
+        q_head_input = torch.cat([hidden_state, onehot, continuous_param.to(hidden_state.dtype)], dim=1)
+        return ops.linear(F.relu(ops.linear(q_head_input, l1.weight, l1.bias)), l2.weight, l2.bias)
 
     def q_values_all_actions(self, hidden_state, continuous_params_all):
         """Q(h, a, P[:, a]) for all a at once, [N, A].  Inference path (no autograd): replaces the
@@ -174,13 +172,13 @@ class QMixer(nn.Module):
         w_cat = torch.cat([self.hyper_w_1[0].weight, self.hyper_w_final[0].weight, self.V[0].weight,
                            self.hyper_b_1.weight], dim=0)
         b_cat = torch.cat([self.hyper_w_1[0].bias, self.hyper_w_final[0].bias, self.V[0].bias, self.hyper_b_1.bias])
-        out = F.linear(s, w_cat, b_cat)                       # [M, 2 Hh + 2 Em]
+        out = ops.linear(s, w_cat, b_cat)                     # [M, 2 Hh + 2 Em]
         # split (backward = ONE cat of the four gradients) rather than slices (backward = a zero-fill + copy per
         # slice plus adds to merge them)
         h_w1, h_wf, h_v, b1_raw = out.split([Hh, Hh, Em, Em], dim=1)
-        w1_raw = self.hyper_w_1[2](F.relu(h_w1))
-        wf_raw = self.hyper_w_final[2](F.relu(h_wf))
-        v_raw = self.V[2](F.relu(h_v))
+        w1_raw = ops.linear(F.relu(h_w1), self.hyper_w_1[2].weight, self.hyper_w_1[2].bias)
+        wf_raw = ops.linear(F.relu(h_wf), self.hyper_w_final[2].weight, self.hyper_w_final[2].bias)
+        v_raw = ops.linear(F.relu(h_v), self.V[2].weight, self.V[2].bias)
         return w1_raw, b1_raw, wf_raw, v_raw
 
     def forward(self, agent_qs, states):

@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(64 * NW) gru_sequence_kernel(const macjd_gru_i
                 w[g][i][kk] = v.x; w[g][i][kk + 1] = v.y; w[g][i][kk + 2] = v.z; w[g][i][kk + 3] = v.w;
             }
         }
-    float bias[3][U], h[U], gcur[3][U], gnext[3][U];
+    float bias[3][U], h[U], gcur[3][U], gnext[3][U], gnext2[3][U];   // gi ring: steps t, t+1, t+2
 #pragma unroll
     for (int i = 0; i < U; ++i) {
         const int u = lane + 64 * i;
@@ -216,19 +216,24 @@ __global__ void __launch_bounds__(64 * NW) gru_sequence_kernel(const macjd_gru_i
     auto gi_row = [&](int t) { return gi + (((int64_t)b * T + t) * io.J + j) * (3 * H); };
     if (T > 0) {
         const float* r0 = gi_row(0);
+        const float* r1 = gi_row(T > 1 ? 1 : 0);
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
-            for (int i = 0; i < U; ++i) gcur[g][i] = r0[g * H + lane + 64 * i];
+            for (int i = 0; i < U; ++i) {
+                gcur[g][i] = r0[g * H + lane + 64 * i];
+                gnext[g][i] = r1[g * H + lane + 64 * i];
+            }
     }
 
     for (int t = 0; t < T; ++t) {
-        if (t + 1 < T) {  // prefetch the next step's input transform (independent of the recurrence)
-            const float* rn = gi_row(t + 1);
+        {   // prefetch the input transform TWO steps ahead (independent of the recurrence): one step (< 1 us) does
+            // not cover a global-load miss, and the wait for it sits on the critical path
+            const float* rn = gi_row(t + 2 < T ? t + 2 : T - 1);
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
-                for (int i = 0; i < U; ++i) gnext[g][i] = rn[g * H + lane + 64 * i];
+                for (int i = 0; i < U; ++i) gnext2[g][i] = rn[g * H + lane + 64 * i];
         }
         float acc[3][U];
 #pragma unroll
@@ -280,7 +285,7 @@ __global__ void __launch_bounds__(64 * NW) gru_sequence_kernel(const macjd_gru_i
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
-            for (int i = 0; i < U; ++i) gcur[g][i] = gnext[g][i];
+            for (int i = 0; i < U; ++i) { gcur[g][i] = gnext[g][i]; gnext[g][i] = gnext2[g][i]; }
     }
 }
 

@@ -1,0 +1,151 @@
+// macjd_wgrad.hip — split-K weight / bias gradient of a Linear layer on exact-f32 MFMA.  C-ABI: include/macjd_nets.h
+//
+//   dW[M,N] = gout[K,M]^T x inp[K,N]      db[M] = sum_k gout[k,:]
+//
+// In the learner's backward these products have tiny outputs (hyper-network and Q-head weights, 64..384 x 46..128)
+// and a long reduction (K = B (T+1) = 3232 mixer rows, or B (T+1) J = 9696 agent rows).  A library GEMM tiles the
+// OUTPUT, i.e. runs them on 6..12 workgroups for 25..50 us each; here the REDUCTION is tiled:
+//   * grid = (N tiles, M tiles, K chunks), 64 x 64 output tile x 128-row chunk per workgroup (4 waves as 2 x 2,
+//     32 x 32 per wave = 2 x 2 accumulators of v_mfma_f32_16x16x4_f32);
+//   * both operand chunks are staged into LDS with coalesced 16-byte loads, [128][80] floats each (row pitch
+//     80 = 16 mod 32: the fragment reads `chunk[4 kk + (lane >> 4)][16 t + (lane & 15)]` of both operands hit 32
+//     distinct banks per 32-lane group);
+//   * the chunk's partial tile goes to workspace[chunk][M][N]; the bias partial (column sums of the staged gout
+//     chunk) is produced by the workgroups of N-tile 0;
+//   * wgrad_reduce_kernel sums the chunks in index order (deterministic, no float atomics).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/macjd.h"
+#include "../../include/macjd_nets.h"
+#include "macjd_err.h"
+
+namespace macjd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int WG_BM = 64, WG_BN = 64, WG_KC = 128, WG_PITCH = 80;
+
+__host__ __device__ inline int64_t wg_pad(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+__global__ void __launch_bounds__(256) wgrad_partial_kernel(const macjd_wgrad_io io, const int Mp, const int Np) {
+    __shared__ float sA[WG_KC * WG_PITCH];   // gout chunk  [k][m]
+    __shared__ float sB[WG_KC * WG_PITCH];   // inp chunk   [k][n]
+    const int tn = blockIdx.x, tm = blockIdx.y, chunk = blockIdx.z;
+    const int m0 = tm * WG_BM, n0 = tn * WG_BN;
+    const int64_t k0 = (int64_t)chunk * WG_KC;
+    const int tid = threadIdx.x;
+    // ---- stage both chunks: 128 rows x 64 columns, 16 threads per row, 16-byte loads where aligned ----
+    const bool a_vec = ((io.gout_ld & 3) == 0) && ((((uintptr_t)io.gout) & 15) == 0);
+    const bool b_vec = ((io.inp_ld & 3) == 0) && ((((uintptr_t)io.inp) & 15) == 0);
+#pragma unroll
+    for (int it = 0; it < (WG_KC * 16) / 256; ++it) {
+        const int idx = it * 256 + tid;
+        const int r = idx >> 4, c4 = (idx & 15) * 4;
+        const int64_t k = k0 + r;
+        float4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+        if (k < io.K) {
+            const float* ga = io.gout + k * io.gout_ld + m0 + c4;
+            if (a_vec && m0 + c4 + 3 < io.M) va = *reinterpret_cast<const float4*>(ga);
+            else {
+                if (m0 + c4 + 0 < io.M) va.x = ga[0];
+                if (m0 + c4 + 1 < io.M) va.y = ga[1];
+                if (m0 + c4 + 2 < io.M) va.z = ga[2];
+                if (m0 + c4 + 3 < io.M) va.w = ga[3];
+            }
+            const float* gb = io.inp + k * io.inp_ld + n0 + c4;
+            if (b_vec && n0 + c4 + 3 < io.N) vb = *reinterpret_cast<const float4*>(gb);
+            else {
+                if (n0 + c4 + 0 < io.N) vb.x = gb[0];
+                if (n0 + c4 + 1 < io.N) vb.y = gb[1];
+                if (n0 + c4 + 2 < io.N) vb.z = gb[2];
+                if (n0 + c4 + 3 < io.N) vb.w = gb[3];
+            }
+        }
+        *reinterpret_cast<float4*>(&sA[r * WG_PITCH + c4]) = va;
+        *reinterpret_cast<float4*>(&sB[r * WG_PITCH + c4]) = vb;
+    }
+    __syncthreads();
+    // ---- 32 x 32 per wave: acc[sm][sn] += A^T fragment x B fragment over the chunk ----
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* pa = sA + lk * WG_PITCH + wm + li;
+    const float* pb = sB + lk * WG_PITCH + wn + li;
+#pragma unroll 8
+    for (int kk = 0; kk < WG_KC / 4; ++kk) {
+        const float a0 = pa[kk * 4 * WG_PITCH], a1 = pa[kk * 4 * WG_PITCH + 16];
+        const float b0 = pb[kk * 4 * WG_PITCH], b1 = pb[kk * 4 * WG_PITCH + 16];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    float* ws = io.workspace + (int64_t)chunk * Mp * Np;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm + a * 16 + lk * 4 + r;   // C layout: row = (lane >> 4) * 4 + reg
+                const int n = n0 + wn + b * 16 + li;           //           col = lane & 15
+                ws[(int64_t)m * Np + n] = acc[a][b][r];
+            }
+    // ---- bias partial: column sums of the staged gout chunk (N-tile 0 only) ----
+    if (io.db && tn == 0 && tid < WG_BM) {
+        float s = 0.0f;
+#pragma unroll 8
+        for (int r = 0; r < WG_KC; ++r) s += sA[r * WG_PITCH + tid];
+        io.workspace[(int64_t)gridDim.z * Mp * Np + (int64_t)chunk * Mp + m0 + tid] = s;
+    }
+}
+
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const macjd_wgrad_io io, const int Mp, const int Np,
+                                                           const int n_chunks) {
+    const int64_t total = (int64_t)io.M * io.N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total + io.M; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < total) {
+            const int m = (int)(i / io.N), n = (int)(i - (int64_t)m * io.N);
+            float s = 0.0f;
+            for (int c = 0; c < n_chunks; ++c) s += io.workspace[((int64_t)c * Mp + m) * Np + n];
+            io.dW[(int64_t)m * io.dw_ld + n] = s;
+        } else if (io.db) {
+            const int m = (int)(i - total);
+            float s = 0.0f;
+            for (int c = 0; c < n_chunks; ++c) s += io.workspace[(int64_t)n_chunks * Mp * Np + (int64_t)c * Mp + m];
+            io.db[m] = s;
+        }
+    }
+}
+
+}  // namespace macjd
+
+extern "C" int64_t macjd_linear_wgrad_workspace_floats(int64_t K, int32_t M, int32_t N) {
+    using namespace macjd;
+    if (K < 1 || M < 1 || N < 1) return -1;
+    const int64_t chunks = (K + WG_KC - 1) / WG_KC, Mp = wg_pad(M, WG_BM), Np = wg_pad(N, WG_BN);
+    return chunks * Mp * Np + chunks * Mp;
+}
+
+extern "C" int macjd_linear_wgrad(const macjd_wgrad_io* io, void* hip_stream) {
+    using namespace macjd;
+    if (!io || io->K < 1 || io->M < 1 || io->N < 1 || !io->gout || !io->inp || !io->dW || !io->workspace)
+        return set_err(MACJD_EINVAL, "%s", "macjd_linear_wgrad: bad argument");
+    if (io->gout_ld < io->M || io->inp_ld < io->N || io->dw_ld < io->N)
+        return set_err(MACJD_EINVAL, "%s", "macjd_linear_wgrad: bad leading dimension");
+    const int Mp = (int)wg_pad(io->M, WG_BM), Np = (int)wg_pad(io->N, WG_BN);
+    const int64_t chunks = (io->K + WG_KC - 1) / WG_KC;
+    if (chunks > 65535) return set_err(MACJD_EUNSUPPORTED, "%s", "macjd_linear_wgrad: K too large");
+    hipStream_t s = (hipStream_t)hip_stream;
+    hipLaunchKernelGGL(wgrad_partial_kernel, dim3(Np / WG_BN, Mp / WG_BM, (unsigned)chunks), dim3(256), 0, s, *io, Mp, Np);
+    const int64_t total = (int64_t)io->M * io->N + io->M;
+    const unsigned rblocks = (unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, s, *io, Mp, Np, (int)chunks);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_linear_wgrad: %s", hipGetErrorString(err));
+    return MACJD_OK;
+}

@@ -399,3 +399,53 @@ def gather_rows(idx, srcs, dsts):
         io.dst_row_bytes[k] = d_.stride(0) * d_.element_size()   # destination rows may be longer (padded steps)
     with torch.cuda.device(idx.device):
         _native.check(lib.macjd_gather_rows(ctypes.byref(io), _stream(idx)), "macjd_gather_rows")
+
+
+# ---------------------------------------------------------------------------------------------
+# Linear with a split-K MFMA weight / bias gradient (csrc/macjd_wgrad.hip)
+def linear_wgrad(gout, inp, want_bias=True):
+    """dW [M,N] = gout[K,M]^T inp[K,N], db [M] = column sums of gout (HIP device, float32, row-strided inputs)."""
+    lib = _native.load()
+    gout, inp = _f32c(gout), _f32c(inp)
+    K, M = gout.shape
+    N = inp.shape[1]
+    dW = torch.empty((M, N), dtype=torch.float32, device=gout.device)
+    db = torch.empty((M,), dtype=torch.float32, device=gout.device) if want_bias else None
+    ws = torch.empty(int(lib.macjd_linear_wgrad_workspace_floats(K, M, N)), dtype=torch.float32, device=gout.device)
+    io = _native.WgradIO()
+    io.K, io.M, io.N = K, M, N
+    io.gout, io.gout_ld, io.inp, io.inp_ld = gout.data_ptr(), gout.stride(0), inp.data_ptr(), inp.stride(0)
+    io.dW, io.dw_ld, io.db, io.workspace = dW.data_ptr(), dW.stride(0), (db.data_ptr() if want_bias else None), ws.data_ptr()
+    with torch.cuda.device(gout.device):
+        _native.check(lib.macjd_linear_wgrad(ctypes.byref(io), _stream(gout)), "macjd_linear_wgrad")
+    return dW, db
+
+
+class _LinearSplitK(torch.autograd.Function):
+    """y = x W^T + b.  Forward and the input gradient are library GEMMs; the weight / bias gradients, tiny outputs
+    reduced over thousands of rows, run on the split-K MFMA kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gx = gy.matmul(weight) if ctx.needs_input_grad[0] else None
+        gW = gb = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gW, gb = linear_wgrad(gy.reshape(-1, gy.shape[-1]), x.reshape(-1, x.shape[-1]), want_bias=ctx.has_bias)
+        return gx, gW, (gb if ctx.has_bias else None)
+
+
+def linear(x, weight, bias=None):
+    """torch.nn.functional.linear with the split-K weight gradient when it pays: HIP device, autograd on, and a
+    reduction of >= 1024 rows into a small weight."""
+    if (x.is_cuda and torch.is_grad_enabled() and (weight.requires_grad or (bias is not None and bias.requires_grad))
+            and x.dtype == torch.float32 and x.numel() // x.shape[-1] >= 1024 and weight.shape[0] * weight.shape[1] <= 384 * 256
+            and x.stride(-1) == 1):
+        return _LinearSplitK.apply(x, weight, bias)
+    return F.linear(x, weight, bias)

@@ -55,6 +55,12 @@ def main():
                    acts[l]) for l in range(len(dims) - 1)]
         cases[name + " | fused MFMA"] = lambda x=x, layers=layers: ops.mlp_forward(x, layers)
         cases[name + " | torch GEMMs"] = lambda x=x, layers=layers: ops.mlp_reference(x, layers)
+    # learner GRU scan: 2 networks x 96 sequences x 100 steps, H = 64
+    B, T, J, H = 32, 100, 3, 64
+    gis = [torch.randn(B, T, J, 3 * H, device=dev) for _ in range(2)]
+    ws = [torch.randn(3 * H, H, device=dev) / 8 for _ in range(2)]
+    bs = [torch.randn(3 * H, device=dev) * 0.1 for _ in range(2)]
+    cases["GRU scan 2x96 seq x 100 steps | fused kernel"] = lambda: ops.gru_sequence_multi(gis, ws, bs)
     with torch.no_grad():
         res = {k: [] for k in cases}
         for _ in range(args.rounds):
