@@ -442,9 +442,9 @@ class _LinearSplitK(torch.autograd.Function):
 
 
 def linear(x, weight, bias=None):
-    """torch.nn.functional.linear with the split-K weight gradient when it pays: HIP device, autograd on, and a
-    reduction of >= 1024 rows into a small weight."""
-    if (x.is_cuda and torch.is_grad_enabled() and (weight.requires_grad or (bias is not None and bias.requires_grad))
+    """torch.nn.functional.linear with the split-K weight gradient when it pays: HIP device, autograd on, float32
+    (not under the optional bf16 autocast of the mixer), and a reduction of >= 1024 rows into a small weight."""
+    if (x.is_cuda and torch.is_grad_enabled() and not torch.is_autocast_enabled() and (weight.requires_grad or (bias is not None and bias.requires_grad))
             and x.dtype == torch.float32 and x.numel() // x.shape[-1] >= 1024 and weight.shape[0] * weight.shape[1] <= 384 * 256
             and x.stride(-1) == 1):
         return _LinearSplitK.apply(x, weight, bias)
