@@ -350,25 +350,42 @@ class QMixLearner:
         per-step / per-action unroll of qmix.py:217-280 (the discarded ``params`` tensor is not built).
         Everything but the recurrence is time-parallel: one GEMM each for fc1, the GRU input transform,
         the actor layers and the Q-head base over all B*T*J rows; the recurrences of all controllers
-        (eval + target) run in ONE fused scan launch.  Leaves each controller's ``hidden_states`` at the
-        final h_T like the reference's loop does."""
+        (eval + target) run in ONE fused scan launch.  The scan is a latency-bound chain that leaves most of
+        the chip idle, so on a HIP device the actor chains — which do not depend on it — run concurrently on a
+        forked side stream (also inside a captured graph: fork / join by stream waits).  Leaves each controller's
+        ``hidden_states`` at the final h_T like the reference's loop does."""
         B, T, J, S = obs.shape
         rows = obs.reshape(B * T * J, S)
-        gis = []
-        for m in macs:
-            a = m.agent
-            gis.append(a.gru_input_transform(rows).view(B, T, J, 3 * a.rnn_hidden_dim))  # networks.py:100
+        side = None
+        if rows.is_cuda:
+            if getattr(self, "_side_stream", None) is None:
+                self._side_stream = torch.cuda.Stream(device=rows.device)
+            side, main = self._side_stream, torch.cuda.current_stream(rows.device)
+            side.wait_stream(main)                                           # fork
+            with torch.cuda.stream(side):
+                params = [m.agent.actor_forward(rows) for m in macs]         # networks.py:127
+        else:
+            params = [m.agent.actor_forward(rows) for m in macs]
+        gis = [m.agent.gru_input_transform(rows).view(B, T, J, 3 * m.agent.rnn_hidden_dim) for m in macs]  # networks.py:100
         h_alls = ops.gru_sequence_multi(gis, [m.agent.rnn.weight_hh for m in macs],
                                         [m.agent.rnn.bias_hh for m in macs])  # h_0 = 0 (qmix.py:241)
-        out = []
+        bases = []
         for m, h_all in zip(macs, h_alls):
             a = m.agent
-            H, A = a.rnn_hidden_dim, a.n_actions
+            H = a.rnn_hidden_dim
             m.hidden_states = h_all[:, T - 1].reshape(B * J, H) if T > 0 else None
-            params_all = a.actor_forward(rows)                               # networks.py:127
+            l1 = a.fc2_q_head[0]
+            bases.append(F.linear(h_all.reshape(B * T * J, H), l1.weight[:, :H], l1.bias))
+        if side is not None:
+            torch.cuda.current_stream(rows.device).wait_stream(side)        # join
+            for p in params:
+                p.record_stream(torch.cuda.current_stream(rows.device))
+        out = []
+        for m, base, params_all in zip(macs, bases, params):
+            a = m.agent
             l1, l2 = a.fc2_q_head[0], a.fc2_q_head[2]
-            base = F.linear(h_all.reshape(B * T * J, H), l1.weight[:, :H], l1.bias)
-            out.append(ops.qhead_all_actions(base, params_all, l1.weight, l2.weight, l2.bias, H, A).view(B, T, J, A))
+            out.append(ops.qhead_all_actions(base, params_all, l1.weight, l2.weight, l2.bias, a.rnn_hidden_dim,
+                                             a.n_actions).view(B, T, J, a.n_actions))
         return out
 
     def _all_action_q(self, mac_controller, obs):

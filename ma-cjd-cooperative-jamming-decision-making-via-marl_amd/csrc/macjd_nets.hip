@@ -175,6 +175,14 @@ extern "C" int macjd_qhead_select(const macjd_qhead_io* io, void* hip_stream) {
 //   * gi for step t+1 is loaded while step t computes; wave 0 stores h' (256-B coalesced rows).
 namespace macjd {
 
+__device__ __forceinline__ float gru_sigmoid(float x) {
+    return __frcp_rn(1.0f + __expf(-x));
+}
+__device__ __forceinline__ float gru_tanh(float x) {
+    // tanh(x) = 1 - 2 / (exp(2x) + 1); saturates cleanly: exp -> inf gives 1, exp -> 0 gives -1
+    return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f);
+}
+
 template <int H, int NW>
 __global__ void __launch_bounds__(64 * NW) gru_sequence_kernel(const macjd_gru_io io) {
     constexpr int U = H / 64;    // hidden units per lane
@@ -272,9 +280,12 @@ __global__ void __launch_bounds__(64 * NW) gru_sequence_kernel(const macjd_gru_i
                 for (int ww = 0; ww < NW; ++ww) s += s_part[buf][ww][g][u];
                 gh[g] = s + bias[g][i];
             }
-            const float r = 1.0f / (1.0f + expf(-(gcur[0][i] + gh[0])));
-            const float z = 1.0f / (1.0f + expf(-(gcur[1][i] + gh[1])));
-            const float n = tanhf(gcur[2][i] + r * gh[2]);
+            // sigmoid / tanh on the hardware exp2 + rcp units (~1 ulp each) instead of IEEE division + libm tanhf:
+            // these sit on the strictly sequential per-step chain (about a third of its instructions); the 1e-5
+            // tolerance on h after T = 100 steps is checked against the step-by-step float32 reference
+            const float r = gru_sigmoid(gcur[0][i] + gh[0]);
+            const float z = gru_sigmoid(gcur[1][i] + gh[1]);
+            const float n = gru_tanh(gcur[2][i] + r * gh[2]);
             h[i] = (h[i] - n) * z + n;
         }
         if (wave == 0) {
