@@ -208,29 +208,17 @@ class QMixLearner:
         B, T1 = st["state"].shape[0], T + 1
         J, H = self.n_agents, self.args.rnn_hidden_dim
         rollout_hidden = self.mac.hidden_states
-        n = B * T1 * J
-        dev = st["state"].device
-        main = torch.cuda.current_stream(dev)
-        if getattr(self, "_side_stream2", None) is None:
-            self._side_stream2 = torch.cuda.Stream(device=dev)
-        side2 = self._side_stream2
-        # The differentiable half (Q of the taken actions from BUFFERED hidden states, eval mixer) does not depend
-        # on the no-grad unroll, whose GRU scan leaves most of the chip idle: fork it onto a side stream (autograd
-        # runs each node's backward on its forward stream and joins with the caller's stream when backward returns).
-        side2.wait_stream(main)
-        with torch.cuda.stream(side2):
-            q_taken = self.mac.agent.get_q_value_for_action(
-                st["hidden_state"].view(n, H), st["actions_discrete"].view(n, 1), st["actions_continuous"].view(n, 1),
-                validate=False).view(B, T1, J)                                          # qmix.py:161-184
-            eval_q_tot = self.eval_qmix_net(q_taken, st["state"])                      # [B,T+1,1], qmix.py:187
         with torch.no_grad():
             target_q_all, eval_q_all = self._all_action_q_multi([self.target_mac, self.mac], st["obs"])  # [B,T+1,J,A]
             self.mac.hidden_states = rollout_hidden
             next_actions = eval_q_all.argmax(dim=3, keepdim=True)                      # qmix.py:138-143 (no mask)
             target_q_taken = torch.gather(target_q_all, 3, next_actions).squeeze(3)    # qmix.py:147
             target_q_tot = self.target_qmix_net(target_q_taken, st["state"])           # [B,T+1,1], qmix.py:151
-        main.wait_stream(side2)                                                        # join
-        eval_q_tot.record_stream(main)
+        n = B * T1 * J
+        q_taken = self.mac.agent.get_q_value_for_action(
+            st["hidden_state"].view(n, H), st["actions_discrete"].view(n, 1), st["actions_continuous"].view(n, 1),
+            validate=False).view(B, T1, J)                                              # qmix.py:161-184
+        eval_q_tot = self.eval_qmix_net(q_taken, st["state"])                          # [B,T+1,1], qmix.py:187
         # loss over eval steps 0..T-2 against targets built from target steps 1..T-1 (qmix.py:155,190-194)
         loss, eval_mean, target_mean = ops.td_loss_full(eval_q_tot, target_q_tot, st["reward"], st["terminated"],
                                                         st["filled"], self.args.gamma, T - 1, 1)
