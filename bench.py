@@ -231,7 +231,7 @@ def main():
         }
         if sweep:
             res["env_kernel_sweep"] = sweep
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N=1 only
             cb = cpu_baseline(sc, E, seed=42)
             res["cpu_baseline"] = {
                 "value": round(cb["all"][0], 1), "unit": "env-steps/s", "cores": cb["all"][1], "kind": "port",
