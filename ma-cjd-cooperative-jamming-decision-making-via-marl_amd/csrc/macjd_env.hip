@@ -270,6 +270,15 @@ __global__ void __launch_bounds__(64 * (NJW + NRW)) env_step_slots_kernel(const 
     // ---------------- phase 1: jammer lanes, environment.py:248-302 ----------------
     double my_prj[JPW];
     int my_meta[JPW];
+    double u_radar[RPW];   // radar waves are idle in phase 1: they draw their detection uniforms now (the draws
+                           // depend only on (env, step, slot), not on the actions), off the post-barrier path
+    if (!jam_wave) {
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = (wave - NJW) + rr * NRW;
+            u_radar[rr] = (r < R) ? draw_uniform(io, e, r, (uint32_t)step_before) : 2.0;
+        }
+    }
     if (jam_wave) {
 #pragma unroll
         for (int jj = 0; jj < JPW; ++jj) {
@@ -365,8 +374,7 @@ __global__ void __launch_bounds__(64 * (NJW + NRW)) env_step_slots_kernel(const 
                 const double den = tb->D[r] * supp + Pn;
                 const double snr_with = (den > 1e-18) ? tb->GaPs[r] / den : 0.0;
                 const double pd = det_prob(snr_with, pdA, pdc1, pdden);
-                const double u = draw_uniform(io, e, r, (uint32_t)step_before);
-                const bool tracking = (u <= pd);  // next FSM state == detected (radar.py:102-117)
+                const bool tracking = (u_radar[rr] <= pd);  // next FSM state == detected (radar.py:102-117)
                 const double red = tb->pd_no[r] - pd;
                 s_rd[r][lane] = tracking ? tb->rd_pen[r] : 0.0;
                 s_rjs[r][lane] = (targeted && red > 0.0) ? red : 0.0;

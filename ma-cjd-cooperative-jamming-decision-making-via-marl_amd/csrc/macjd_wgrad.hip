@@ -104,20 +104,37 @@ __global__ void __launch_bounds__(256) wgrad_partial_kernel(const macjd_wgrad_io
     }
 }
 
+// Sum of the K-chunk partials, fixed order (deterministic).  8 lanes share one output element: lane s of the group adds
+// chunks s, s+8, s+16, ... (independent loads in flight), then a 3-step xor-shuffle tree combines the 8 partial sums.
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const macjd_wgrad_io io, const int Mp, const int Np,
                                                            const int n_chunks) {
     const int64_t total = (int64_t)io.M * io.N;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total + io.M; i += (int64_t)gridDim.x * blockDim.x) {
+    const int sub = threadIdx.x & 7;
+    const int64_t groups_per_block = blockDim.x >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * groups_per_block + (threadIdx.x >> 3); i < total + io.M;
+         i += (int64_t)gridDim.x * groups_per_block) {
+        float s = 0.0f;
         if (i < total) {
             const int m = (int)(i / io.N), n = (int)(i - (int64_t)m * io.N);
-            float s = 0.0f;
-            for (int c = 0; c < n_chunks; ++c) s += io.workspace[((int64_t)c * Mp + m) * Np + n];
-            io.dW[(int64_t)m * io.dw_ld + n] = s;
+            const float* p = io.workspace + (int64_t)m * Np + n;
+#pragma unroll 4
+            for (int c = sub; c < n_chunks; c += 8) s += p[(int64_t)c * Mp * Np];
         } else if (io.db) {
             const int m = (int)(i - total);
-            float s = 0.0f;
-            for (int c = 0; c < n_chunks; ++c) s += io.workspace[(int64_t)n_chunks * Mp * Np + (int64_t)c * Mp + m];
-            io.db[m] = s;
+            const float* p = io.workspace + (int64_t)n_chunks * Mp * Np + m;
+#pragma unroll 4
+            for (int c = sub; c < n_chunks; c += 8) s += p[(int64_t)c * Mp];
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (sub == 0) {
+            if (i < total) {
+                const int m = (int)(i / io.N), n = (int)(i - (int64_t)m * io.N);
+                io.dW[(int64_t)m * io.dw_ld + n] = s;
+            } else if (io.db) {
+                io.db[i - total] = s;
+            }
         }
     }
 }
@@ -142,8 +159,8 @@ extern "C" int macjd_linear_wgrad(const macjd_wgrad_io* io, void* hip_stream) {
     if (chunks > 65535) return set_err(MACJD_EUNSUPPORTED, "%s", "macjd_linear_wgrad: K too large");
     hipStream_t s = (hipStream_t)hip_stream;
     hipLaunchKernelGGL(wgrad_partial_kernel, dim3(Np / WG_BN, Mp / WG_BM, (unsigned)chunks), dim3(256), 0, s, *io, Mp, Np);
-    const int64_t total = (int64_t)io->M * io->N + io->M;
-    const unsigned rblocks = (unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    const int64_t total = (int64_t)io->M * io->N + io->M;   // 8 lanes per output element -> 32 outputs per block
+    const unsigned rblocks = (unsigned)((total + 31) / 32 < 2048 ? (total + 31) / 32 : 2048);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, s, *io, Mp, Np, (int)chunks);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_linear_wgrad: %s", hipGetErrorString(err));
