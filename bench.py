@@ -196,6 +196,45 @@ def main():
                                    "traffic": pmc_traffic(J, R, Eb)[0]}
         eb.close()
         del eb, Tb, Pb
+    # ---- MFMA-bound kernel of the path: the actor's fused dense chain (exact-f32 v_mfma_f32_16x16x4_f32) ----
+    roofline_mfma = None
+    if rank == 0:
+        try:
+            from macjd_amd import ops
+            A_, S_, N_rows = 2 * R + 1, sc.state_dim, E * J
+            dims = (S_, 128, 128, A_)
+            if ops.mlp_supported(list(dims)):
+                xs = torch.randn(N_rows, S_, device=dev)
+                layers = [(torch.randn(dims[l + 1], dims[l], device=dev) / dims[l] ** 0.5,
+                           torch.randn(dims[l + 1], device=dev) * 0.1, (1, 1, 2)[l]) for l in range(3)]
+                with torch.no_grad():
+                    side = torch.cuda.Stream(device=dev)
+                    side.wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(side):
+                        for _ in range(3):
+                            ops.mlp_forward(xs, layers)
+                    torch.cuda.current_stream(dev).wait_stream(side)
+                    gr = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gr):
+                        for _ in range(20):
+                            ops.mlp_forward(xs, layers)
+                    gr.replay()
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(10):
+                        gr.replay()
+                    e1.record()
+                    torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) / 200 * 1e3
+                flops = 2.0 * N_rows * (dims[0] * dims[1] + dims[1] * dims[2] + dims[2] * dims[3])
+                tf = flops / (us * 1e-6) / 1e12
+                roofline_mfma = {"bound": "mfma", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s",
+                                 "frac": round(tf / 157.3, 4), "traffic": None,
+                                 "kernel": "mlp_pack_kernel + mlp_forward_kernel (actor %d-%d-%d-%d, %d rows)" % (*dims, N_rows),
+                                 "us_per_call": round(us, 2), "flops_per_call": int(flops), "dtype": "f32 (exact-f32 MFMA)"}
+        except Exception as ex:  # the HBM roofline above is the contract item; this one is additional
+            roofline_mfma = {"error": str(ex)[:200]}
     sweep = None
     if args.sweep and rank == 0:
         sweep = []
@@ -229,6 +268,8 @@ def main():
                        "mode": mode, "per_gpu_env_steps_per_s": round(E * args.steps / dt, 1), **extra},
             "roofline": roofline,
         }
+        if roofline_mfma is not None:
+            res["roofline_mfma"] = roofline_mfma
         if sweep:
             res["env_kernel_sweep"] = sweep
         if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N=1 only
