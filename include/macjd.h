@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MACJD_ABI_VERSION 1
+#define MACJD_ABI_VERSION 2
 
 #define MACJD_OK          0
 #define MACJD_EINVAL     -1  /* bad argument (shape, NULL, stride)            */
@@ -126,6 +126,9 @@ typedef struct macjd_step_io {
     double*  prj64;      /* [E,J] contiguous: received jamming power of jammer j's action if it
                             was recorded in info['jammer_actions'] (environment.py:288-295),
                             else -1; may be NULL */
+    float*   r_dpj_sum;  /* [E,3] contiguous, optional: (r_d, r_p, r_j) of this step are ADDED to it — the
+                            per-episode sums behind run_info['avg_r_d'|'avg_r_p'|'avg_r_j']
+                            (runners/episode_runner.py:88-90,141-143) without a separate launch */
 } macjd_step_io;
 
 /* library / device */

@@ -13,7 +13,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libmacjd_hip.so"
 LIB_PATH = os.path.join(_PKG_DIR, LIB_NAME)
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 STEP_ARITH_F64 = 1
 STEP_LANE_KERNEL = 2
 STEP_SLOT_KERNEL = 4
@@ -46,7 +46,7 @@ class StepIO(ctypes.Structure):
         ("pd", ctypes.c_void_p), ("pd_se", ctypes.c_int64), ("pd_sx", ctypes.c_int64),
         ("snr_with", ctypes.c_void_p), ("sw_se", ctypes.c_int64), ("sw_sx", ctypes.c_int64),
         ("out64", ctypes.c_void_p), ("pd64", ctypes.c_void_p), ("snr64", ctypes.c_void_p),
-        ("prj64", ctypes.c_void_p),
+        ("prj64", ctypes.c_void_p), ("r_dpj_sum", ctypes.c_void_p),
     ]
 
 

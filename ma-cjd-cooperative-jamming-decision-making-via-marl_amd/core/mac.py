@@ -39,6 +39,9 @@ class BasicMAC:
         # (eps float32[1], counter int64[1]) device tensors; when set, the fused select kernel reads the
         # exploration probability / Philox call counter from them (HIP-graph replay, see BatchedEpisodeRunner)
         self.device_schedule = None
+        # optional (int32 [E,J,1], float32 [E,J,1]) destinations for the chosen actions of the NEXT select_actions call
+        # on a HIP device (the batched runner points them at its staging rows: no copy, the env kernel reads them there)
+        self.action_out = None
 
     def select_actions(self, obs_batch, avail_actions_batch, t_env, test_mode=False):
         device = next(self.agent.parameters()).device
@@ -66,7 +69,10 @@ class BasicMAC:
                 T64, P_sel, T32, Q = ops.qhead_select(
                     base, params_all, l1.weight, l2.weight, l2.bias, H, A, self.n_agents, avail_actions_batch,
                     epsilon=eps, greedy_only=test_mode, seed=self.select_seed, counter=counter,
-                    want_q=self.keep_q_values, eps_dev=eps_dev, counter_dev=ctr_dev)
+                    want_q=self.keep_q_values, eps_dev=eps_dev, counter_dev=ctr_dev,
+                    out_T32=self.action_out[0] if self.action_out else None,
+                    out_P=self.action_out[1] if self.action_out else None)
+                self.action_out = None
                 self.last_actions_T32, self.last_actions_P = T32, P_sel
                 self.last_q_values = Q.view(batch_size, self.n_agents, A) if Q is not None else None
                 return T64, P_sel

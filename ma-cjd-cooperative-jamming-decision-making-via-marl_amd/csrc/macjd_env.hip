@@ -220,6 +220,11 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
             io.r_dpj[e * 3 + 1] = (float)r_p;
             io.r_dpj[e * 3 + 2] = (float)r_j;
         }
+        if (io.r_dpj_sum) {
+            io.r_dpj_sum[e * 3 + 0] += (float)r_d;
+            io.r_dpj_sum[e * 3 + 1] += (float)r_p;
+            io.r_dpj_sum[e * 3 + 2] += (float)r_j;
+        }
         if (io.out64) {
             io.out64[e * 4 + 0] = reward;
             io.out64[e * 4 + 1] = r_d;
@@ -430,6 +435,11 @@ __global__ void __launch_bounds__(64 * (NJW + NRW)) env_step_slots_kernel(const 
             io.r_dpj[e * 3 + 0] = (float)r_d;
             io.r_dpj[e * 3 + 1] = (float)r_p;
             io.r_dpj[e * 3 + 2] = (float)r_j;
+        }
+        if (io.r_dpj_sum) {
+            io.r_dpj_sum[e * 3 + 0] += (float)r_d;
+            io.r_dpj_sum[e * 3 + 1] += (float)r_p;
+            io.r_dpj_sum[e * 3 + 2] += (float)r_j;
         }
         if (io.out64) {
             io.out64[e * 4 + 0] = reward;

@@ -61,7 +61,8 @@ def qhead_all_actions(base, P_all, W1, w2, b2, H: int, A: int) -> torch.Tensor:
 
 def qhead_select(base, P_all, W1, w2, b2, H: int, A: int, n_agents: int, avail: Optional[torch.Tensor],
                  epsilon: float, greedy_only: bool, seed: int, counter: int, want_q: bool = False,
-                 eps_dev: Optional[torch.Tensor] = None, counter_dev: Optional[torch.Tensor] = None
+                 eps_dev: Optional[torch.Tensor] = None, counter_dev: Optional[torch.Tensor] = None,
+                 out_T32: Optional[torch.Tensor] = None, out_P: Optional[torch.Tensor] = None
                  ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
     """Fused all-action Q + mask + epsilon-greedy + gather on a HIP device.
 
@@ -77,9 +78,19 @@ def qhead_select(base, P_all, W1, w2, b2, H: int, A: int, n_agents: int, avail: 
     dev = base.device
     base, P_all, W1 = _f32c(base.detach()), _f32c(P_all.detach()), _f32c(W1.detach())
     w2, b2 = w2.detach().reshape(-1).contiguous(), b2.detach().reshape(-1).contiguous()
-    T32 = torch.empty((n_agents, E), dtype=torch.int32, device=dev)
+    # chosen actions: agent-major scratch by default; or straight into caller-provided [E, J(,1)] tensors of any
+    # strides (e.g. the runner's staging row, which the env-step kernel then reads in place)
+    if out_T32 is not None:
+        T32v = out_T32.view(E, n_agents) if out_T32.dim() == 3 else out_T32
+        assert T32v.dtype == torch.int32 and tuple(T32v.shape) == (E, n_agents) and T32v.device == dev
+    else:
+        T32v = torch.empty((n_agents, E), dtype=torch.int32, device=dev).t()
+    if out_P is not None:
+        Pv = out_P.view(E, n_agents) if out_P.dim() == 3 else out_P
+        assert Pv.dtype == torch.float32 and tuple(Pv.shape) == (E, n_agents) and Pv.device == dev
+    else:
+        Pv = torch.empty((n_agents, E), dtype=torch.float32, device=dev).t()
     T64 = torch.empty((E, n_agents, 1), dtype=torch.int64, device=dev)
-    P_am = torch.empty((n_agents, E), dtype=torch.float32, device=dev)
     Q = torch.empty((N, A), dtype=torch.float32, device=dev) if want_q else None
     io = _native.QheadIO()
     _qhead_fill(io, base, P_all, W1, w2, b2, H, A, n_agents)
@@ -100,12 +111,12 @@ def qhead_select(base, P_all, W1, w2, b2, H: int, A: int, n_agents: int, avail: 
     if counter_dev is not None:  # int64 [1] on the device: added to ``counter`` at run time
         assert counter_dev.dtype == torch.int64 and counter_dev.device == dev
         io.counter_dev = counter_dev.data_ptr()
-    io.T_out32, io.t32_se, io.t32_sj = T32.data_ptr(), 1, E
+    io.T_out32, io.t32_se, io.t32_sj = T32v.data_ptr(), T32v.stride(0), T32v.stride(1)
     io.T_out64, io.t64_se, io.t64_sj = T64.data_ptr(), n_agents, 1
-    io.P_out, io.po_se, io.po_sj = P_am.data_ptr(), 1, E
+    io.P_out, io.po_se, io.po_sj = Pv.data_ptr(), Pv.stride(0), Pv.stride(1)
     with torch.cuda.device(dev):
         _native.check(lib.macjd_qhead_select(ctypes.byref(io), _stream(base)), "macjd_qhead_select")
-    return T64, P_am.t().unsqueeze(-1), T32.t(), Q
+    return T64, Pv.unsqueeze(-1), T32v, Q
 
 
 def gru_sequence_reference(gi: torch.Tensor, w_hh: torch.Tensor, b_hh: torch.Tensor,

@@ -217,14 +217,21 @@ class BatchedEpisodeRunner:
         # exploration draws are keyed by (seed; row, counter) with counter = ep * (T + 1) + t + 1, the same in
         # eager and graph-replayed rollouts (select_actions pre-increments its call counter)
         mac._select_calls = self._ep * (self.episode_limit + 1) + t
+        on_device = self._obs.is_cuda
+        if on_device:   # the fused select kernel writes the chosen actions straight into this step's staging rows
+            mac.action_out = (st["actions_discrete"][t], st["actions_continuous"][t])
         T64, P_sel = mac.select_actions(self._obs, self._avail, self.t_env, test_mode=test_mode)
         st["hidden_state"][t].copy_(mac.hidden_states.view(E, J, -1))  # post-update h_t
-        T32 = mac.last_actions_T32 if mac.last_actions_T32 is not None else T64.squeeze(-1).to(torch.int32)
-        st["actions_discrete"][t].copy_(T32.unsqueeze(-1))
-        st["actions_continuous"][t].copy_(P_sel)
+        if on_device:
+            T32, P_sel = st["actions_discrete"][t], st["actions_continuous"][t]
+        else:
+            T32 = mac.last_actions_T32 if mac.last_actions_T32 is not None else T64.squeeze(-1).to(torch.int32)
+            st["actions_discrete"][t].copy_(T32.view(E, J, 1))
+            st["actions_continuous"][t].copy_(P_sel)
+        # the env kernel reads the actions from the staging row, writes reward / terminated into their rows and adds
+        # (r_d, r_p, r_j) to the running per-episode sums
         env.step(T32, P_sel, out_reward=st["reward"][t].view(E), out_terminated=st["terminated"][t].view(E),
-                 want_info=False)
-        self._rdpj_sum += env._r_dpj
+                 want_info=False, rdpj_sum=self._rdpj_sum)
         self.t_env += 1
         if not self._static:
             self._obs, self._avail = env.get_obs(), env.get_avail_actions()

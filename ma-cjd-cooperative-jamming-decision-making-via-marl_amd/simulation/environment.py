@@ -142,7 +142,7 @@ class BatchedElectromagneticEnvironment:
     # ---- the hot call ----
     def _fill_io(self, T: torch.Tensor, P: torch.Tensor, u: Optional[torch.Tensor], arith_f64: bool,
                  reward: Optional[torch.Tensor], terminated: Optional[torch.Tensor], want_info: bool,
-                 diag: Optional[Dict[str, torch.Tensor]]) -> _native.StepIO:
+                 diag: Optional[Dict[str, torch.Tensor]], rdpj_sum: Optional[torch.Tensor] = None) -> _native.StepIO:
         E, R, J = self.batch_envs, self.num_radars, self.num_jammers
         if T.dim() == 3:
             T = T.squeeze(-1)
@@ -190,6 +190,7 @@ class BatchedElectromagneticEnvironment:
             io.snr_with, io.sw_se, io.sw_sx = None, 0, 0
         for k in ("out64", "pd64", "snr64", "prj64"):
             setattr(io, k, diag[k].data_ptr() if diag is not None else None)
+        io.r_dpj_sum = rdpj_sum.data_ptr() if rdpj_sum is not None else None
         # keep converted tensors alive until the launch has been enqueued (same-stream ordering
         # keeps their storage valid for the kernel: the caching allocator is stream-ordered)
         self._keep = (T, P, u, rew, ter, diag)
@@ -198,7 +199,7 @@ class BatchedElectromagneticEnvironment:
     def step(self, actions_T: torch.Tensor, actions_P: torch.Tensor, uniforms: Optional[torch.Tensor] = None,
              *, arith_f64: bool = False, out_reward: Optional[torch.Tensor] = None,
              out_terminated: Optional[torch.Tensor] = None, want_info: bool = True,
-             diag: Optional[Dict[str, torch.Tensor]] = None
+             diag: Optional[Dict[str, torch.Tensor]] = None, rdpj_sum: Optional[torch.Tensor] = None
              ) -> Tuple[torch.Tensor, torch.Tensor, Dict[str, torch.Tensor]]:
         """One step of all E envs (batched environment.py:221-477).
 
@@ -210,7 +211,11 @@ class BatchedElectromagneticEnvironment:
         the next ``step`` overwrites (pass ``out_reward`` / ``out_terminated`` to write elsewhere,
         e.g. straight into a replay row).  No host synchronisation happens here.
         """
-        io = self._fill_io(actions_T, actions_P, uniforms, arith_f64, out_reward, out_terminated, want_info, diag)
+        if rdpj_sum is not None and not (rdpj_sum.dtype == torch.float32 and rdpj_sum.is_contiguous()
+                                         and tuple(rdpj_sum.shape) == (self.batch_envs, 3) and rdpj_sum.device == self.device):
+            raise ValueError(f"rdpj_sum must be a contiguous float32 [{self.batch_envs}, 3] tensor on {self.device}")
+        io = self._fill_io(actions_T, actions_P, uniforms, arith_f64, out_reward, out_terminated, want_info, diag,
+                           rdpj_sum)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         with torch.cuda.device(self.device):
             _native.check(self._lib.macjd_env_step(self._handle.ptr, ctypes.byref(io), stream), "macjd_env_step")

@@ -34,6 +34,7 @@ static macjd_step_io slice(const macjd_scenario_desc* d, const macjd_step_io* io
     if (s.pd64) s.pd64 += lo * R;
     if (s.snr64) s.snr64 += lo * R;
     if (s.prj64) s.prj64 += lo * J;
+    if (s.r_dpj_sum) s.r_dpj_sum += lo * 3;
     return s;
 }
 

@@ -217,6 +217,32 @@ def test_reset_mask_and_outputs_into_caller_buffers():
     assert int(env.track[::3].sum()) == 0
 
 
+def test_reward_component_sums_accumulate_in_kernel():
+    """rdpj_sum += (r_d, r_p, r_j) inside the step launch (lane and slot kernels) == summing the per-step
+    r_dpj output; the actions are read from a strided [E,J,1] view like the runner's staging rows."""
+    sc, _ = load_scenario("3j4r")
+    R, J, E = sc.num_radars, sc.num_jammers, 777
+    rng = np.random.default_rng(9)
+    from macjd_amd import _native
+    for flag in (_native.STEP_LANE_KERNEL, _native.STEP_SLOT_KERNEL):
+        env = _env(sc, E, seed=11)
+        env.kernel_flags = flag
+        env.reset()
+        acc = torch.zeros((E, 3), device="cuda")
+        ref = torch.zeros((E, 3), device="cuda")
+        stage_T = torch.zeros((5, E, J, 1), dtype=torch.int32, device="cuda")
+        stage_P = torch.zeros((5, E, J, 1), device="cuda")
+        for t in range(5):
+            T, P = random_actions(rng, E, J, R, with_invalid=False)
+            stage_T[t].copy_(torch.from_numpy(T).view(E, J, 1))
+            stage_P[t].copy_(torch.from_numpy(P).view(E, J, 1))
+            env.step(stage_T[t], stage_P[t], rdpj_sum=acc)
+            ref += env._r_dpj
+        assert torch.equal(acc, ref) and float(acc.abs().sum()) > 0
+    with pytest.raises(ValueError):
+        env.step(stage_T[0], stage_P[0], rdpj_sum=torch.zeros((E, 2), device="cuda"))
+
+
 def test_bad_arguments_raise():
     sc, _ = load_scenario("3j4r")
     env = _env(sc, 8)

@@ -71,6 +71,29 @@ def test_fused_qhead_vs_oracle(tag, N_envs):
     assert (avail.reshape(N, -1)[np.arange(N), got_T] == 1).all()
 
 
+def test_fused_selection_writes_into_caller_rows():
+    """out_T32 / out_P: the select kernel stores the chosen actions into caller-provided [E,J,1] rows (the runner's
+    staging tensors) — same values as the default agent-major scratch outputs."""
+    from macjd_amd import ops
+    E, J, A, H = 513, 3, 9, 64
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    base = torch.randn(E * J, H, generator=gen).to(DEV)
+    P = torch.rand(E * J, A, generator=gen).to(DEV)
+    W1 = (0.2 * torch.randn(H, H + A + 1, generator=gen)).to(DEV)
+    w2, b2 = torch.randn(1, H, generator=gen).to(DEV), torch.zeros(1, device=DEV)
+    avail = (torch.rand(E, J, A, generator=gen) < 0.8).to(torch.int32).to(DEV)
+    avail[..., 0] = 1
+    kw = dict(epsilon=0.25, greedy_only=False, seed=7, counter=3)
+    T64, Psel, T32, _ = ops.qhead_select(base, P, W1, w2, b2, H, A, J, avail, **kw)
+    stage_T = torch.full((2, E, J, 1), -7, dtype=torch.int32, device=DEV)
+    stage_P = torch.full((2, E, J, 1), -7.0, device=DEV)
+    T64b, Pb, T32b, _ = ops.qhead_select(base, P, W1, w2, b2, H, A, J, avail, out_T32=stage_T[1], out_P=stage_P[1], **kw)
+    assert torch.equal(T64, T64b)
+    assert torch.equal(stage_T[1], T64.to(torch.int32)) and torch.equal(stage_P[1], Psel.contiguous())
+    assert Pb.data_ptr() == stage_P[1].data_ptr() and T32b.data_ptr() == stage_T[1].data_ptr()
+    assert int((stage_T[0] != -7).sum()) == 0 and int((stage_P[0] != -7.0).sum()) == 0
+
+
 def test_fused_selection_exploration_statistics():
     """epsilon-greedy in-kernel: P(explore) ~ eps, uniform over AVAILABLE actions, deterministic per
     (seed, counter), different across counters."""
