@@ -231,7 +231,7 @@ def main():
                 tf = flops / (us * 1e-6) / 1e12
                 roofline_mfma = {"bound": "mfma", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s",
                                  "frac": round(tf / 157.3, 4), "traffic": None,
-                                 "kernel": "mlp_pack_kernel + mlp_forward_kernel (actor %d-%d-%d-%d, %d rows)" % (*dims, N_rows),
+                                 "kernel": "mlp_forward_kernel (actor %d-%d-%d-%d, %d rows)" % (*dims, N_rows),
                                  "us_per_call": round(us, 2), "flops_per_call": int(flops), "dtype": "f32 (exact-f32 MFMA)"}
         except Exception as ex:  # the HBM roofline above is the contract item; this one is additional
             roofline_mfma = {"error": str(ex)[:200]}

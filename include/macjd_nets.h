@@ -193,8 +193,8 @@ int macjd_gather_rows(const macjd_gather_io* io, void* hip_stream);
  *   fc1 + GRU input transform Linear-ReLU-Linear (W_ih x + b_ih)       (core/networks.py:100, GRUCell)
  * in the rollout (core/mac.py:168-187) and in the learner's time-parallel unroll (core/qmix.py:241-253).
  * W_l is torch.nn.Linear's [out, in] row-major weight.  Limits: dims[0] <= 256, hidden widths <= 128, last
- * width <= 384, one layer's packed weights + the activation strips <= 160 KB of LDS; MACJD_EUNSUPPORTED
- * otherwise.
+ * width <= 384, ceil(width / 16) in {1,2,3,4,8,12,24}, one layer's LDS weight image (rows padded to a pitch of
+ * 32 m + 2 floats) + the activation strips <= 160 KB of LDS; MACJD_EUNSUPPORTED otherwise.
  */
 #define MACJD_ACT_NONE 0
 #define MACJD_ACT_RELU 1
@@ -210,10 +210,8 @@ typedef struct macjd_mlp_io {
     float* y;        int64_t y_ld;   /* [n_rows, dims[n_layers]] */
 } macjd_mlp_io;
 
-/* Floats of device workspace macjd_mlp_forward needs for this io (packed MFMA weight fragments); < 0 on
-   a malformed io.  The workspace is caller-owned (no allocation inside the call: graph-capture safe). */
-int64_t macjd_mlp_workspace_floats(const macjd_mlp_io* io);
-int macjd_mlp_forward(const macjd_mlp_io* io, float* workspace, void* hip_stream);
+/* One launch, no workspace: the weights are read in torch's own [out, in] layout (LDS-DMA into padded LDS rows). */
+int macjd_mlp_forward(const macjd_mlp_io* io, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,7 @@ EXPORTS = [
     "macjd_scenario_create", "macjd_scenario_destroy", "macjd_scenario_dims",
     "macjd_env_reset", "macjd_env_step", "macjd_env_step_timed",
     "macjd_qhead_select", "macjd_gru_sequence", "macjd_mixer_tail_forward", "macjd_mixer_tail_backward",
-    "macjd_mlp_forward", "macjd_mlp_workspace_floats", "macjd_td_loss", "macjd_clip_adam_step", "macjd_gather_rows",
+    "macjd_mlp_forward", "macjd_td_loss", "macjd_clip_adam_step", "macjd_gather_rows",
     "macjd_linear_wgrad", "macjd_linear_wgrad_workspace_floats",
 ]
 
@@ -184,9 +184,7 @@ def load() -> ctypes.CDLL:
         getattr(lib, name).restype = ctypes.c_int
         getattr(lib, name).argtypes = [ctypes.POINTER(MixerIO), ctypes.c_void_p]
     lib.macjd_mlp_forward.restype = ctypes.c_int
-    lib.macjd_mlp_forward.argtypes = [ctypes.POINTER(MlpIO), ctypes.c_void_p, ctypes.c_void_p]
-    lib.macjd_mlp_workspace_floats.restype = ctypes.c_int64
-    lib.macjd_mlp_workspace_floats.argtypes = [ctypes.POINTER(MlpIO)]
+    lib.macjd_mlp_forward.argtypes = [ctypes.POINTER(MlpIO), ctypes.c_void_p]
     lib.macjd_td_loss.restype = ctypes.c_int
     lib.macjd_td_loss.argtypes = [ctypes.POINTER(TdLossIO), ctypes.c_void_p]
     lib.macjd_clip_adam_step.restype = ctypes.c_int

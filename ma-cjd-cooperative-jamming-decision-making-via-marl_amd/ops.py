@@ -276,8 +276,12 @@ def mlp_reference(x, layers):
     return x
 
 
+def _mlp_pitch(width: int) -> int:
+    return ((width + 7) // 16) * 16 + 8
+
+
 def mlp_supported(dims) -> bool:
-    """Shape limits of macjd_mlp_forward (see include/macjd_nets.h)."""
+    """Shape limits of macjd_mlp_forward (see include/macjd_nets.h; mirrors the host checks in csrc/macjd_mlp.hip)."""
     L = len(dims) - 1
     if not (1 <= L <= 3) or dims[0] > 256:
         return False
@@ -288,8 +292,9 @@ def mlp_supported(dims) -> bool:
             return False
         if (N + 15) // 16 not in (1, 2, 3, 4, 8, 12, 24):
             return False
-        biggest = max(biggest, ((N + 15) // 16) * ((K + 3) // 4) * 64)
-    lda = ((max(dims[:-1]) + 31) // 32) * 32 + 2
+        n16, k16 = (N + 15) // 16 * 16, (K + 15) // 16 * 16
+        biggest = max(biggest, n16 * _mlp_pitch(k16) + n16)
+    lda = _mlp_pitch((max(dims[:-1]) + 15) // 16 * 16)
     return biggest <= _MLP_LDS_FLOATS - 4 * 16 * lda
 
 
@@ -313,9 +318,8 @@ def mlp_forward(x, layers):
         io.dims[l], io.W[l], io.b[l], io.act[l] = dims[l], w.data_ptr(), b.data_ptr(), int(act)
     io.dims[len(layers)] = dims[-1]
     io.x, io.x_ld, io.y, io.y_ld = x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0)
-    ws = torch.empty(int(lib.macjd_mlp_workspace_floats(ctypes.byref(io))), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _native.check(lib.macjd_mlp_forward(ctypes.byref(io), ws.data_ptr(), _stream(x)), "macjd_mlp_forward")
+        _native.check(lib.macjd_mlp_forward(ctypes.byref(io), _stream(x)), "macjd_mlp_forward")
     return y
 
 
