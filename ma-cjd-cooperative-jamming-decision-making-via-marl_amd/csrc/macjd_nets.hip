@@ -10,6 +10,10 @@
 // W1[:, H+A] and w2 are wave-uniform, so they arrive through scalar loads (s_load) and feed the VALU
 // as SGPR operands; the only vector memory traffic is the row's own base[H] (16-B loads), its P[A]
 // and the outputs.  The A accumulators live in registers (kernel templated on A).
+// At rollout / learner sizes (~10^4 rows) that is one wave per CU grinding through H x A serial
+// iterations, so for small batches a workgroup is HS = 4 waves over the SAME 64 rows, wave w taking the
+// hidden units [w H/4, (w+1) H/4) (weights stay wave-uniform); the partial sums meet in LDS and are
+// added in fixed wave order by wave 0, which then does the selection (14 us -> 6 us at 12 288 rows).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -31,24 +35,34 @@ __device__ __forceinline__ bool avail_at(const macjd_qhead_io& io, int64_t e, in
                                      : (((const int32_t*)io.avail)[off] != 0);
 }
 
-template <int AT>
+constexpr int QHEAD_HS = 4;   // hidden-unit splits (waves per 64 rows) of the small-batch launch
+
+template <int AT, int HS>
 __global__ void __launch_bounds__(256) qhead_select_kernel(const macjd_qhead_io io) {
     constexpr int AMAX = AT ? AT : 64;
     const int A = AT ? AT : io.A;
     const int H = io.H;
-    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= io.n_rows) return;
+    // HS == 1: every thread is a row.  HS > 1: blockDim = 64 * HS, lane = row within the workgroup's 64 rows,
+    // wave = hidden-unit split
+    const int wave = (HS > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+    const int64_t n = (HS > 1) ? (int64_t)blockIdx.x * 64 + (threadIdx.x & 63)
+                               : (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool row_live = n < io.n_rows;
+    if (HS == 1 && !row_live) return;
+    __shared__ float s_part[(HS > 1) ? (HS - 1) * AMAX * 64 : 1];
+    const int h_chunk = (HS > 1) ? (((H + HS - 1) / HS + 3) & ~3) : H;   // multiple of 4: keeps the 16-B loads
+    const int h_lo = wave * h_chunk, h_hi = (h_lo + h_chunk < H) ? h_lo + h_chunk : H;
 
     float p[AMAX], acc[AMAX];
 #pragma unroll
     for (int a = 0; a < AMAX; ++a) {
-        const bool live = AT || a < A;
+        const bool live = (AT || a < A) && row_live;
         p[a] = live ? io.P_all[n * io.p_ld + a] : 0.0f;
         acc[a] = 0.0f;
     }
-    const float* __restrict__ brow = io.base + n * io.base_ld;
+    const float* __restrict__ brow = io.base + (row_live ? n : 0) * io.base_ld;
     const bool vec4 = ((io.base_ld & 3) == 0) && ((((uintptr_t)io.base) & 15) == 0);
-    for (int h0 = 0; h0 < H; h0 += 4) {
+    for (int h0 = h_lo; h0 < h_hi; h0 += 4) {
         float b4[4];
         if (vec4 && h0 + 4 <= H) {
             const float4 v = *reinterpret_cast<const float4*>(brow + h0);
@@ -74,6 +88,25 @@ __global__ void __launch_bounds__(256) qhead_select_kernel(const macjd_qhead_io 
                 acc[a] = fmaf(t, w2h, acc[a]);    // second layer (networks.py:78)
             }
         }
+    }
+    if (HS > 1) {   // partial sums of waves 1..HS-1 -> LDS; wave 0 adds them in wave order and carries on alone
+        const int lane = threadIdx.x & 63;
+        if (wave > 0) {
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) {
+                if (!AT && a >= A) break;
+                s_part[((wave - 1) * AMAX + a) * 64 + lane] = acc[a];
+            }
+        }
+        __syncthreads();
+        if (wave > 0 || !row_live) return;
+#pragma unroll
+        for (int w = 0; w < HS - 1; ++w)
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) {
+                if (!AT && a >= A) break;
+                acc[a] += s_part[(w * AMAX + a) * 64 + lane];
+            }
     }
     const float b2 = io.b2[0];
 #pragma unroll
@@ -142,18 +175,28 @@ extern "C" int macjd_qhead_select(const macjd_qhead_io* io, void* hip_stream) {
     if (io->avail && io->avail_elem_size != 4 && io->avail_elem_size != 8)
         return set_nets_err(MACJD_EINVAL, "macjd_qhead_select: avail_elem_size must be 4 or 8");
     if (io->n_rows == 0) return MACJD_OK;
-    // small batches: one wave per workgroup so the rows spread over more CUs
-    const int block = io->n_rows >= (1 << 16) ? 256 : 64;
-    const dim3 g((unsigned)((io->n_rows + block - 1) / block)), b(block);
     hipStream_t s = (hipStream_t)hip_stream;
+    // small batches: 64 rows per workgroup, hidden units split over QHEAD_HS waves; large ones: 256 rows per
+    // workgroup, one lane does its whole row
+    const bool split = io->n_rows < (1 << 16) && io->H >= 16;
+#define MACJD_QHEAD_LAUNCH(AT)                                                                                    \
+    do {                                                                                                          \
+        if (split)                                                                                                \
+            hipLaunchKernelGGL((qhead_select_kernel<AT, QHEAD_HS>), dim3((unsigned)((io->n_rows + 63) / 64)),     \
+                               dim3(64 * QHEAD_HS), 0, s, *io);                                                   \
+        else                                                                                                      \
+            hipLaunchKernelGGL((qhead_select_kernel<AT, 1>), dim3((unsigned)((io->n_rows + 255) / 256)), dim3(256), \
+                               0, s, *io);                                                                        \
+    } while (0)
     switch (io->A) {
-        case 5:  hipLaunchKernelGGL((qhead_select_kernel<5>), g, b, 0, s, *io); break;
-        case 7:  hipLaunchKernelGGL((qhead_select_kernel<7>), g, b, 0, s, *io); break;
-        case 9:  hipLaunchKernelGGL((qhead_select_kernel<9>), g, b, 0, s, *io); break;
-        case 17: hipLaunchKernelGGL((qhead_select_kernel<17>), g, b, 0, s, *io); break;
-        case 33: hipLaunchKernelGGL((qhead_select_kernel<33>), g, b, 0, s, *io); break;
-        default: hipLaunchKernelGGL((qhead_select_kernel<0>), g, b, 0, s, *io); break;
+        case 5:  MACJD_QHEAD_LAUNCH(5); break;
+        case 7:  MACJD_QHEAD_LAUNCH(7); break;
+        case 9:  MACJD_QHEAD_LAUNCH(9); break;
+        case 17: MACJD_QHEAD_LAUNCH(17); break;
+        case 33: MACJD_QHEAD_LAUNCH(33); break;
+        default: MACJD_QHEAD_LAUNCH(0); break;
     }
+#undef MACJD_QHEAD_LAUNCH
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
     return MACJD_OK;
