@@ -75,8 +75,10 @@ typedef struct macjd_gru_io {
     const float* gi[2];    /* [B,T,J,3H] */
     const float* w_hh[2];  /* rnn.weight_hh [3H,H] row-major */
     const float* b_hh[2];  /* rnn.bias_hh [3H] */
-    const float* h0[2];    /* optional initial state [B*J,H]; NULL = zeros (mac.init_hidden) */
+    const float* h0[2];    /* optional initial state [B,J,H]; NULL = zeros (mac.init_hidden) */
     float* h_out[2];       /* [B,T,J,H] */
+    int64_t h0_sb[2];      /* element stride between batch entries of h0 (0 = J*H, contiguous): lets the caller pass
+                              step 0 of a stored [B,T+1,J,H] hidden-state tensor without copying it */
 } macjd_gru_io;
 
 int macjd_gru_sequence(const macjd_gru_io* io, void* hip_stream);
@@ -86,7 +88,8 @@ int macjd_gru_sequence(const macjd_gru_io* io, void* hip_stream);
  *   w1 = clamp(w1_raw, 0, 5) [J,Em]   b1 = clamp(b1_raw, -5, 5) [Em]   wf = clamp(wf_raw, 0, 5) [Em]
  *   v = clamp(v_raw, -5, 5)           hid = q . w1 + b1                y = ELU(hid) . wf + v
  * (torch.bmm([M,1,J],[M,J,Em]) / F.elu / torch.bmm([M,1,Em],[M,Em,1]) in the reference) and its backward
- * (clamp passes the gradient where min <= x <= max, like torch.clamp).  All tensors contiguous float32.
+ * (clamp passes the gradient where min <= x <= max, like torch.clamp).  All tensors contiguous float32 (b1_raw may
+ * have a row stride).
  * Forward needs q, w1_raw, b1_raw, wf_raw, v_raw, y.  Backward additionally gy and the five gradient outputs.
  */
 typedef struct macjd_mixer_io {
@@ -104,6 +107,8 @@ typedef struct macjd_mixer_io {
     float* gb1_raw;         /* [M,Em]   */
     float* gwf_raw;         /* [M,Em]   */
     float* gv_raw;          /* [M]      */
+    int64_t b1_ld;          /* row stride of b1_raw in elements (0 = Em): b1_raw may be a column block of the merged
+                               first-layer output */
 } macjd_mixer_io;
 
 int macjd_mixer_tail_forward(const macjd_mixer_io* io, void* hip_stream);
@@ -185,6 +190,41 @@ typedef struct macjd_gather_io {
 } macjd_gather_io;
 
 int macjd_gather_rows(const macjd_gather_io* io, void* hip_stream);
+
+/*
+ * Input rows of the Q-head for the TAKEN action, out[n, :] = [h[n, 0..H-1], onehot_A(idx[n]), P[n]]  — the
+ * torch.full / F.one_hot / torch.cat sequence of RNNAgent.get_q_value_for_action (reference core/networks.py:160-172)
+ * as one launch.  idx outside [0, A) gives an all-zero one-hot block (the caller validates indices when asked to).
+ */
+typedef struct macjd_qinput_io {
+    int64_t n_rows;
+    int32_t H, A;
+    const float* h;   int64_t h_ld;      /* [n_rows, H] */
+    const void* idx;  int32_t idx_elem_size, reserved;   /* [n_rows] int32 (4) or int64 (8), contiguous */
+    const float* P;                      /* [n_rows] contiguous */
+    float* out;       int64_t out_ld;    /* [n_rows, H + A + 1] */
+} macjd_qinput_io;
+
+int macjd_qhead_input(const macjd_qinput_io* io, void* hip_stream);
+
+/*
+ * LayerNorm forward over the last dimension (QMixer.state_norm, reference core/networks.py:215,283):
+ *   mean = sum(x)/S, var = sum((x-mean)^2)/S (biased, two-pass), rstd = rsqrt(var + eps), y = (x-mean) rstd gamma + beta.
+ * mean / rstd [M] are saved for torch's native_layer_norm_backward.  S <= 1024.
+ */
+typedef struct macjd_layernorm_io {
+    int64_t M;
+    int32_t S, reserved;
+    float eps, reserved2;
+    const float* x;  int64_t x_ld;
+    const float* gamma;   /* [S] or NULL (= 1) */
+    const float* beta;    /* [S] or NULL (= 0) */
+    float* y;        int64_t y_ld;
+    float* mean;          /* [M], optional */
+    float* rstd;          /* [M], optional */
+} macjd_layernorm_io;
+
+int macjd_layernorm_forward(const macjd_layernorm_io* io, void* hip_stream);
 
 /*
  * Fused chain of up to three dense layers, y = act_n(W_n ... act_1(W_1 x + b_1) ... + b_n), float32 with

@@ -24,7 +24,7 @@ EXPORTS = [
     "macjd_env_reset", "macjd_env_step", "macjd_env_step_timed",
     "macjd_qhead_select", "macjd_gru_sequence", "macjd_mixer_tail_forward", "macjd_mixer_tail_backward",
     "macjd_mlp_forward", "macjd_td_loss", "macjd_clip_adam_step", "macjd_gather_rows",
-    "macjd_linear_wgrad", "macjd_linear_wgrad_workspace_floats",
+    "macjd_linear_wgrad", "macjd_linear_wgrad_workspace_floats", "macjd_qhead_input", "macjd_layernorm_forward",
 ]
 
 
@@ -77,7 +77,7 @@ class GruIO(ctypes.Structure):
         ("n_nets", ctypes.c_int32), ("B", ctypes.c_int32), ("T", ctypes.c_int32), ("J", ctypes.c_int32),
         ("H", ctypes.c_int32), ("reserved", ctypes.c_int32),
         ("gi", ctypes.c_void_p * 2), ("w_hh", ctypes.c_void_p * 2), ("b_hh", ctypes.c_void_p * 2),
-        ("h0", ctypes.c_void_p * 2), ("h_out", ctypes.c_void_p * 2),
+        ("h0", ctypes.c_void_p * 2), ("h_out", ctypes.c_void_p * 2), ("h0_sb", ctypes.c_int64 * 2),
     ]
 
 
@@ -89,6 +89,27 @@ class MixerIO(ctypes.Structure):
         ("wf_raw", ctypes.c_void_p), ("v_raw", ctypes.c_void_p), ("y", ctypes.c_void_p),
         ("gy", ctypes.c_void_p), ("gq", ctypes.c_void_p), ("gw1_raw", ctypes.c_void_p),
         ("gb1_raw", ctypes.c_void_p), ("gwf_raw", ctypes.c_void_p), ("gv_raw", ctypes.c_void_p),
+        ("b1_ld", ctypes.c_int64),
+    ]
+
+
+class QinputIO(ctypes.Structure):
+    """ctypes mirror of ``macjd_qinput_io`` (include/macjd_nets.h)."""
+    _fields_ = [
+        ("n_rows", ctypes.c_int64), ("H", ctypes.c_int32), ("A", ctypes.c_int32),
+        ("h", ctypes.c_void_p), ("h_ld", ctypes.c_int64),
+        ("idx", ctypes.c_void_p), ("idx_elem_size", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("P", ctypes.c_void_p), ("out", ctypes.c_void_p), ("out_ld", ctypes.c_int64),
+    ]
+
+
+class LayerNormIO(ctypes.Structure):
+    """ctypes mirror of ``macjd_layernorm_io`` (include/macjd_nets.h)."""
+    _fields_ = [
+        ("M", ctypes.c_int64), ("S", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("eps", ctypes.c_float), ("reserved2", ctypes.c_float),
+        ("x", ctypes.c_void_p), ("x_ld", ctypes.c_int64), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
+        ("y", ctypes.c_void_p), ("y_ld", ctypes.c_int64), ("mean", ctypes.c_void_p), ("rstd", ctypes.c_void_p),
     ]
 
 
@@ -183,6 +204,10 @@ def load() -> ctypes.CDLL:
     for name in ("macjd_mixer_tail_forward", "macjd_mixer_tail_backward"):
         getattr(lib, name).restype = ctypes.c_int
         getattr(lib, name).argtypes = [ctypes.POINTER(MixerIO), ctypes.c_void_p]
+    lib.macjd_qhead_input.restype = ctypes.c_int
+    lib.macjd_qhead_input.argtypes = [ctypes.POINTER(QinputIO), ctypes.c_void_p]
+    lib.macjd_layernorm_forward.restype = ctypes.c_int
+    lib.macjd_layernorm_forward.argtypes = [ctypes.POINTER(LayerNormIO), ctypes.c_void_p]
     lib.macjd_mlp_forward.restype = ctypes.c_int
     lib.macjd_mlp_forward.argtypes = [ctypes.POINTER(MlpIO), ctypes.c_void_p]
     lib.macjd_td_loss.restype = ctypes.c_int

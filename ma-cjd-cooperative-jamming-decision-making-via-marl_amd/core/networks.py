@@ -121,9 +121,7 @@ class RNNAgent(nn.Module):
         l1, l2 = self.fc2_q_head[0], self.fc2_q_head[2]
         # cat([h, onehot(a), P]) -> Linear -> ReLU -> Linear, exactly the reference's formulation (networks.py:171-176);
         # the one-hot is a compare + cast (any integer dtype), the Linears use the split-K weight gradient on a HIP device
-        onehot = (idx.unsqueeze(1) == torch.arange(self.n_actions, device=idx.device, dtype=idx.dtype)) \
-            .to(hidden_state.dtype)
-        q_head_input = torch.cat([hidden_state, onehot, continuous_param.to(hidden_state.dtype)], dim=1)
+        q_head_input = ops.qhead_input(hidden_state, idx, continuous_param, self.n_actions)   # [h, onehot(a), P]
         return ops.linear(F.relu(ops.linear(q_head_input, l1.weight, l1.bias)), l2.weight, l2.bias)
 
     def q_values_all_actions(self, hidden_state, continuous_params_all):
@@ -161,24 +159,59 @@ class QMixer(nn.Module):
         # fp32 accumulation (bf16 MFMA).  Off by default: the reference is fp32 and the 1e-5 tolerance on
         # Q_tot only holds in fp32; LayerNorm and the clamp / ELU tail stay fp32 either way.
         self.bf16_hyper = str(getattr(args, "mixer_dtype", "fp32")).lower() in ("bf16", "bfloat16")
+        self._merged_views = None   # (W_cat, b_cat) views of the learner's flat parameter vector (HIP device)
+        self._cat_cache = None      # persistent concatenated first-layer weights of an inference-only copy
+        self._cat_hooked = False
+
+    def first_layer_params(self):
+        """The four hyper-networks' FIRST Linear layers in merge order: weights, then biases."""
+        mods = (self.hyper_w_1[0], self.hyper_w_final[0], self.V[0], self.hyper_b_1)
+        return [m.weight for m in mods] + [m.bias for m in mods]
+
+    def _refresh_first_layer_cache(self):
+        if self._cat_cache is not None:
+            with torch.no_grad():
+                ps = self.first_layer_params()
+                torch.cat([p.detach() for p in ps[:4]], dim=0, out=self._cat_cache[0])
+                torch.cat([p.detach() for p in ps[4:]], out=self._cat_cache[1])
+
+    def enable_first_layer_cache(self):
+        """Inference-only networks (the target mixer): keep the concatenated first-layer weights in persistent
+        buffers, refilled in place whenever ``load_state_dict`` runs (the target sync) — same addresses, so a
+        captured HIP graph keeps seeing current values."""
+        ps = self.first_layer_params()
+        self._cat_cache = (torch.cat([p.detach() for p in ps[:4]], dim=0), torch.cat([p.detach() for p in ps[4:]]))
+        if not self._cat_hooked:
+            self.register_load_state_dict_post_hook(lambda module, incompatible: module._refresh_first_layer_cache())
+            self._cat_hooked = True
+
+    def _first_layer(self, s):
+        """The four hyper-networks all read the same input, so their FIRST layers run as ONE GEMM over the
+        concatenated weights [Hh + Hh + Em + Em, S] (forward, input-gradient, weight-gradient and bias-gradient
+        each 4 -> 1 launches).  Same dot products as the four separate nn.Linear calls of the reference
+        (networks.py:283-299).  The concatenation itself costs nothing when the learner has laid the parameters
+        out adjacently in its flat vector (``_merged_views``) or, for an inference-only copy, cached it."""
+        if self._merged_views is not None and s.is_cuda and not torch.is_autocast_enabled():
+            w_cat, b_cat = self._merged_views
+            if torch.is_grad_enabled():
+                return ops.merged_linear(s, w_cat, b_cat, self.first_layer_params())
+            return F.linear(s, w_cat, b_cat)
+        if self._cat_cache is not None and not torch.is_grad_enabled() and s.device == self._cat_cache[0].device:
+            return F.linear(s, self._cat_cache[0], self._cat_cache[1])
+        ps = self.first_layer_params()
+        return ops.linear(s, torch.cat(ps[:4], dim=0), torch.cat(ps[4:]))
 
     def _hyper_networks(self, s):
-        """(w1_raw [M,J*Em], b1_raw [M,Em], wf_raw [M,Em], v_raw [M,1]) from the normalised state.
-        The four hyper-networks all read the same input, so their FIRST layers run as ONE GEMM over the
-        concatenated weights [Hh + Hh + Em + Em, S] (forward, input-gradient, weight-gradient and bias-gradient
-        each 4 -> 1 launches; the stacked weight-gradient GEMM has 4x the output tile count of the small ones).
-        Same dot products as the four separate nn.Linear calls of the reference (networks.py:283-299)."""
+        """(w1_raw [M,J*Em], b1_raw [M,Em], wf_raw [M,Em], v_raw [M,1]) from the normalised state."""
         Hh, Em = self.hyper_hidden_dim, self.embed_dim
-        w_cat = torch.cat([self.hyper_w_1[0].weight, self.hyper_w_final[0].weight, self.V[0].weight,
-                           self.hyper_b_1.weight], dim=0)
-        b_cat = torch.cat([self.hyper_w_1[0].bias, self.hyper_w_final[0].bias, self.V[0].bias, self.hyper_b_1.bias])
-        out = ops.linear(s, w_cat, b_cat)                     # [M, 2 Hh + 2 Em]
-        # split (backward = ONE cat of the four gradients) rather than slices (backward = a zero-fill + copy per
-        # slice plus adds to merge them)
-        h_w1, h_wf, h_v, b1_raw = out.split([Hh, Hh, Em, Em], dim=1)
-        w1_raw = ops.linear(F.relu(h_w1), self.hyper_w_1[2].weight, self.hyper_w_1[2].bias)
-        wf_raw = ops.linear(F.relu(h_wf), self.hyper_w_final[2].weight, self.hyper_w_final[2].bias)
-        v_raw = ops.linear(F.relu(h_v), self.V[2].weight, self.V[2].bias)
+        out = self._first_layer(s)                              # [M, 2 Hh + 2 Em]
+        # split (backward = ONE cat) rather than slices (backward = a zero-fill + copy per slice plus adds); the
+        # three ReLUs are one launch over the first 2 Hh + Em columns, b1_raw is the remaining column block
+        pre, b1_raw = out.split([2 * Hh + Em, Em], dim=1)
+        h_w1, h_wf, h_v = F.relu(pre).split([Hh, Hh, Em], dim=1)
+        w1_raw = ops.linear(h_w1, self.hyper_w_1[2].weight, self.hyper_w_1[2].bias)
+        wf_raw = ops.linear(h_wf, self.hyper_w_final[2].weight, self.hyper_w_final[2].bias)
+        v_raw = ops.linear(h_v, self.V[2].weight, self.V[2].bias)
         return w1_raw, b1_raw, wf_raw, v_raw
 
     def forward(self, agent_qs, states):
@@ -186,7 +219,8 @@ class QMixer(nn.Module):
         on the LayerNorm-ed state (networks.py:250-315; note clamp, not abs).  Output shape follows
         the reference: [B, T, 1] for [B, T, J] inputs, [B, 1] for [B, J]."""
         batch_size = agent_qs.size(0)
-        s = self.state_norm(states.reshape(-1, self.state_dim))
+        ln = self.state_norm
+        s = ops.layer_norm(states.reshape(-1, self.state_dim), ln.weight, ln.bias, ln.eps)
         q = agent_qs.reshape(-1, self.n_agents)
         # clamp -> bmm -> ELU -> bmm (+ its backward) is one fused kernel on a HIP device (ops.mixer_tail)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(self.bf16_hyper and s.is_cuda)):

@@ -75,8 +75,13 @@ class QMixLearner:
 
     # ------------------------------------------------------------------ distributed gradients
     def _trainable(self):
-        """Parameters the loss can reach: the Q-head and the mixer (see module docstring)."""
-        return list(self.mac.agent.fc2_q_head.parameters()) + self.qmix_params
+        """Parameters the loss can reach: the Q-head and the mixer (see module docstring), in the order of the
+        flat vectors: the mixer's four first-layer weights, then their biases (adjacent, so that the merged
+        first-layer GEMM reads them as ONE [2Hh+2Em, S] matrix without a torch.cat), then everything else."""
+        first = self.eval_qmix_net.first_layer_params()
+        ids = {id(p) for p in first}
+        rest = [p for p in list(self.mac.agent.fc2_q_head.parameters()) + self.qmix_params if id(p) not in ids]
+        return first + rest
 
     @staticmethod
     def _world_size():
@@ -104,6 +109,13 @@ class QMixLearner:
             self.optimizer.state[p] = {"step": self._adam_step, "exp_avg": self._flat_exp_avg[off:off + n].view_as(p),
                                        "exp_avg_sq": self._flat_exp_avg_sq[off:off + n].view_as(p)}
             off += n
+        # merged first layer of the eval mixer = the leading block of the flat vector; the target mixer (inference
+        # only) keeps a cached concatenation that its load_state_dict refreshes in place
+        mx = self.eval_qmix_net
+        first = mx.first_layer_params()
+        rows, S = sum(p.shape[0] for p in first[:4]), first[0].shape[1]
+        mx._merged_views = (flat[:rows * S].view(rows, S), flat[rows * S:rows * S + rows])
+        self.target_qmix_net.enable_first_layer_cache()
 
     def load_optimizer_state(self, state_dict):
         """``optimizer.load_state_dict`` + re-binding of the loaded moments into the flat vectors."""
@@ -209,7 +221,9 @@ class QMixLearner:
         J, H = self.n_agents, self.args.rnn_hidden_dim
         rollout_hidden = self.mac.hidden_states
         with torch.no_grad():
-            target_q_all, eval_q_all = self._all_action_q_multi([self.target_mac, self.mac], st["obs"])  # [B,T+1,J,A]
+            # [B,T+1,J,A]; the controllers' hidden states are left alone (the rollout owns them)
+            target_q_all, eval_q_all = self._all_action_q_multi([self.target_mac, self.mac], st["obs"],
+                                                                keep_final_hidden=False)
             self.mac.hidden_states = rollout_hidden
             next_actions = eval_q_all.argmax(dim=3, keepdim=True)                      # qmix.py:138-143 (no mask)
             target_q_taken = torch.gather(target_q_all, 3, next_actions).squeeze(3)    # qmix.py:147
@@ -297,6 +311,8 @@ class QMixLearner:
             b = {k: v.index_select(0, self._g_idx) for k, v in zip(keys, srcs)}
             return self._forward_backward(b, self._g_T, validate_actions=False)
 
+        self._graph_body_a = body_a   # kept for scripts/profile_update.py (eager attribution of the captured launches)
+
         # Eager warm-up on a side stream: allocates the optimiser state BEFORE capture (state created during
         # capture would be re-initialised by every replay) and lets the libraries pick their kernels.  The
         # warm-up updates are then undone in place, so enabling graphs does not change the training state.
@@ -345,7 +361,7 @@ class QMixLearner:
         loss, ev, tg = self._g_out_a
         return self._pack_stats(loss, self._g_out_b, ev, tg, sync_stats)
 
-    def _all_action_q_multi(self, macs, obs):
+    def _all_action_q_multi(self, macs, obs, keep_final_hidden=True):
         """Q(s_t, a, P_a(s_t)) for every discrete action, [B, T, J, A] per controller; replaces the
         per-step / per-action unroll of qmix.py:217-280 (the discarded ``params`` tensor is not built).
         Everything but the recurrence is time-parallel: one GEMM each for fc1, the GRU input transform,
@@ -373,7 +389,8 @@ class QMixLearner:
         for m, h_all in zip(macs, h_alls):
             a = m.agent
             H = a.rnn_hidden_dim
-            m.hidden_states = h_all[:, T - 1].reshape(B * J, H) if T > 0 else None
+            if keep_final_hidden:   # the reference's loop leaves h_T behind (a strided slice: this is a copy)
+                m.hidden_states = h_all[:, T - 1].reshape(B * J, H) if T > 0 else None
             l1 = a.fc2_q_head[0]
             bases.append(F.linear(h_all.reshape(B * T * J, H), l1.weight[:, :H], l1.bias))
         if side is not None:

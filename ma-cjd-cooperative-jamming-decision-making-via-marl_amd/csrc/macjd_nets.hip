@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(64 * NW) gru_sequence_kernel(const macjd_gru_i
         const int u = lane + 64 * i;
 #pragma unroll
         for (int g = 0; g < 3; ++g) bias[g][i] = bhh[g * H + u];
-        h[i] = io.h0[net] ? io.h0[net][(int64_t)seq * H + u] : 0.0f;
+        h[i] = io.h0[net] ? io.h0[net][(int64_t)b * (io.h0_sb[net] ? io.h0_sb[net] : (int64_t)io.J * H) + (int64_t)j * H + u] : 0.0f;
     }
     auto gi_row = [&](int t) { return gi + (((int64_t)b * T + t) * io.J + j) * (3 * H); };
     if (T > 0) {
@@ -397,7 +397,7 @@ __global__ void __launch_bounds__(256) mixer_tail_kernel(const macjd_mixer_io io
     const float gy = BACKWARD ? io.gy[m] : 0.0f;
     for (int e = lane; e < ((Em + 63) & ~63); e += 64) {
         const bool live = e < Em;
-        const float b1r = live ? io.b1_raw[m * Em + e] : 0.0f;
+        const float b1r = live ? io.b1_raw[m * (io.b1_ld ? io.b1_ld : (int64_t)Em) + e] : 0.0f;
         const float wfr = live ? io.wf_raw[m * Em + e] : 0.0f;
         float hid = clampf(b1r, -5.0f, 5.0f);
         for (int j = 0; j < J; ++j) {
@@ -638,6 +638,111 @@ extern "C" int macjd_gather_rows(const macjd_gather_io* io, void* hip_stream) {
             return set_nets_err(MACJD_EINVAL, "macjd_gather_rows: bad tensor (row bytes must be a positive multiple of 4)");
     if (io->n_rows == 0) return MACJD_OK;
     hipLaunchKernelGGL(gather_rows_kernel, dim3(8, io->n_tensors, io->n_rows), dim3(256), 0, (hipStream_t)hip_stream, *io);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
+    return MACJD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Q-head input rows for the taken action and LayerNorm forward: two small launch-count savers of the learner update
+// (one launch instead of arange + eq + cast + cat; one launch instead of torch's moments + normalise pair).
+namespace macjd {
+
+__global__ void __launch_bounds__(256) qhead_input_kernel(const macjd_qinput_io io) {
+    const int W = io.H + io.A + 1;
+    const int64_t total = io.n_rows * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / W;
+        const int c = (int)(i - n * W);
+        float v;
+        if (c < io.H) {
+            v = io.h[n * io.h_ld + c];
+        } else if (c < io.H + io.A) {
+            const int64_t a = (io.idx_elem_size == 8) ? ((const int64_t*)io.idx)[n] : (int64_t)((const int32_t*)io.idx)[n];
+            v = (a == (int64_t)(c - io.H)) ? 1.0f : 0.0f;
+        } else {
+            v = io.P[n];
+        }
+        io.out[n * io.out_ld + c] = v;
+    }
+}
+
+// one wave per row (rows strided over the grid's waves); lane l holds columns l, l + 64, ... (S <= 1024)
+__global__ void __launch_bounds__(256) layernorm_forward_kernel(const macjd_layernorm_io io) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int S = io.S;
+    const float inv_s = 1.0f / (float)S;
+    for (int64_t m = wave; m < io.M; m += n_waves) {
+        const float* __restrict__ x = io.x + m * io.x_ld;
+        float v[16];
+        float sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = (c < S) ? x[c] : 0.0f;
+            sum += v[i];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float mean = sum * inv_s;
+        float sq = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = lane + 64 * i;
+            const float d = (c < S) ? v[i] - mean : 0.0f;
+            sq = fmaf(d, d, sq);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        const float rstd = rsqrtf(sq * inv_s + io.eps);
+        float* __restrict__ y = io.y + m * io.y_ld;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = lane + 64 * i;
+            if (c < S) {
+                const float g = io.gamma ? io.gamma[c] : 1.0f, b = io.beta ? io.beta[c] : 0.0f;
+                y[c] = (v[i] - mean) * rstd * g + b;
+            }
+        }
+        if (lane == 0) {
+            if (io.mean) io.mean[m] = mean;
+            if (io.rstd) io.rstd[m] = rstd;
+        }
+    }
+}
+
+}  // namespace macjd
+
+extern "C" int macjd_qhead_input(const macjd_qinput_io* io, void* hip_stream) {
+    using namespace macjd;
+    if (!io || io->n_rows < 0 || io->H < 1 || io->A < 1 || !io->h || !io->idx || !io->P || !io->out)
+        return set_nets_err(MACJD_EINVAL, "macjd_qhead_input: bad argument");
+    if (io->idx_elem_size != 4 && io->idx_elem_size != 8)
+        return set_nets_err(MACJD_EINVAL, "macjd_qhead_input: idx_elem_size must be 4 or 8");
+    if (io->h_ld < io->H || io->out_ld < io->H + io->A + 1)
+        return set_nets_err(MACJD_EINVAL, "macjd_qhead_input: row stride smaller than the row");
+    if (io->n_rows == 0) return MACJD_OK;
+    const int64_t total = io->n_rows * (io->H + io->A + 1);
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(qhead_input_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                       (hipStream_t)hip_stream, *io);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
+    return MACJD_OK;
+}
+
+extern "C" int macjd_layernorm_forward(const macjd_layernorm_io* io, void* hip_stream) {
+    using namespace macjd;
+    if (!io || io->M < 0 || io->S < 1 || io->S > 1024 || !io->x || !io->y)
+        return set_nets_err(MACJD_EINVAL, "macjd_layernorm_forward: bad argument (1 <= S <= 1024)");
+    if (io->x_ld < io->S || io->y_ld < io->S)
+        return set_nets_err(MACJD_EINVAL, "macjd_layernorm_forward: row stride smaller than the row");
+    if (io->M == 0) return MACJD_OK;
+    const int64_t blocks = (io->M + 3) / 4;
+    hipLaunchKernelGGL(layernorm_forward_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0,
+                       (hipStream_t)hip_stream, *io);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
     return MACJD_OK;

@@ -173,7 +173,11 @@ def gru_sequence_multi(gis, w_hhs, b_hhs, h0s=None):
             bb = b_hhs[start + k].detach().float().contiguous()
             h0 = h0s[start + k]
             if h0 is not None:
-                h0 = h0.detach().float().reshape(B * J, H).contiguous()
+                # [B, J, H] with any batch stride (e.g. step 0 of a stored [B, T+1, J, H] tensor): no copy
+                h0 = h0.detach().float().reshape(B, J, H) if h0.dim() != 3 else h0.detach().float()
+                if h0.stride(2) != 1 or h0.stride(1) != H:
+                    h0 = h0.contiguous()
+                io.h0_sb[k] = h0.stride(0)
             o = torch.empty((B, T, J, H), dtype=torch.float32, device=g.device)
             keep += [g, w, bb, h0]
             io.gi[k], io.w_hh[k], io.b_hh[k] = g.data_ptr(), w.data_ptr(), bb.data_ptr()
@@ -204,6 +208,7 @@ def _mixer_io(q, w1_raw, b1_raw, wf_raw, v_raw):
     io.M, io.J, io.Em = q.shape[0], q.shape[1], b1_raw.shape[1]
     io.q, io.w1_raw, io.b1_raw = q.data_ptr(), w1_raw.data_ptr(), b1_raw.data_ptr()
     io.wf_raw, io.v_raw = wf_raw.data_ptr(), v_raw.data_ptr()
+    io.b1_ld = b1_raw.stride(0)      # may be a column block of the merged first-layer output
     return io
 
 
@@ -211,7 +216,8 @@ class _MixerTailHip(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, w1_raw, b1_raw, wf_raw, v_raw):
         lib = _native.load()
-        args = [t.detach().float().contiguous() for t in (q, w1_raw, b1_raw, wf_raw, v_raw)]
+        args = [t.detach().float().contiguous() for t in (q, w1_raw)] + [_f32c(b1_raw.detach())] + \
+               [t.detach().float().contiguous() for t in (wf_raw, v_raw)]
         y = torch.empty((q.shape[0], 1), dtype=torch.float32, device=q.device)
         io = _mixer_io(*args)
         io.y = y.data_ptr()
@@ -225,7 +231,8 @@ class _MixerTailHip(torch.autograd.Function):
         lib = _native.load()
         q, w1_raw, b1_raw, wf_raw, v_raw = ctx.saved_tensors
         gy = gy.detach().float().contiguous()
-        gq, gw1, gb1 = torch.empty_like(q), torch.empty_like(w1_raw), torch.empty_like(b1_raw)
+        gq, gw1 = torch.empty_like(q), torch.empty_like(w1_raw)
+        gb1 = torch.empty(b1_raw.shape, dtype=torch.float32, device=q.device)
         gwf, gv = torch.empty_like(wf_raw), torch.empty_like(v_raw)
         io = _mixer_io(q, w1_raw, b1_raw, wf_raw, v_raw)
         io.gy, io.gq, io.gw1_raw = gy.data_ptr(), gq.data_ptr(), gw1.data_ptr()
@@ -454,6 +461,89 @@ class _LinearSplitK(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gW, gb = linear_wgrad(gy.reshape(-1, gy.shape[-1]), x.reshape(-1, x.shape[-1]), want_bias=ctx.has_bias)
         return gx, gW, (gb if ctx.has_bias else None)
+
+
+class _MergedLinear(torch.autograd.Function):
+    """y = x W_cat^T + b_cat where W_cat / b_cat are VIEWS of a flat parameter vector covering several adjacent
+    Linear layers (no torch.cat per call).  ``params`` = the layers' weights then biases, passed only so that autograd
+    routes the gradients: backward returns row blocks of ONE split-K weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w_cat, b_cat, *params):
+        ctx.save_for_backward(x, w_cat)
+        ctx.sizes = [p.shape[0] for p in params[:len(params) // 2]]
+        return F.linear(x, w_cat, b_cat)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w_cat = ctx.saved_tensors
+        gx = gy.matmul(w_cat) if ctx.needs_input_grad[0] else None
+        gW, gb = linear_wgrad(gy, x, want_bias=True)
+        return (gx, None, None) + tuple(gW.split(ctx.sizes, 0)) + tuple(gb.split(ctx.sizes, 0))
+
+
+def merged_linear(x, w_cat, b_cat, params):
+    return _MergedLinear.apply(x, w_cat, b_cat, *params)
+
+
+def qhead_input(h, idx, P, n_actions: int):
+    """[h, onehot(idx), P] rows for the Q-head, [n, H + A + 1] float32 — one launch on a HIP device (the reference
+    builds it with torch.full / one_hot / cat, core/networks.py:160-172).  Not differentiable (its inputs are data)."""
+    n, H = h.shape
+    if not h.is_cuda:
+        onehot = (idx.reshape(n, 1) == torch.arange(n_actions, device=idx.device, dtype=idx.dtype)).to(h.dtype)
+        return torch.cat([h, onehot, P.reshape(n, 1).to(h.dtype)], dim=1)
+    lib = _native.load()
+    h, P = _f32c(h.detach()), P.detach().float().reshape(n).contiguous()
+    idx = idx.detach().reshape(n)
+    if idx.dtype not in (torch.int32, torch.int64):
+        idx = idx.to(torch.int64)
+    idx = idx.contiguous()
+    out = torch.empty((n, H + n_actions + 1), dtype=torch.float32, device=h.device)
+    io = _native.QinputIO()
+    io.n_rows, io.H, io.A = n, H, int(n_actions)
+    io.h, io.h_ld, io.idx, io.idx_elem_size = h.data_ptr(), h.stride(0), idx.data_ptr(), idx.element_size()
+    io.P, io.out, io.out_ld = P.data_ptr(), out.data_ptr(), out.stride(0)
+    with torch.cuda.device(h.device):
+        _native.check(lib.macjd_qhead_input(ctypes.byref(io), _stream(h)), "macjd_qhead_input")
+    return out
+
+
+class _LayerNormHip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        lib = _native.load()
+        x = _f32c(x.detach())
+        M, S = x.shape
+        y = torch.empty((M, S), dtype=torch.float32, device=x.device)
+        mean = torch.empty((M, 1), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((M, 1), dtype=torch.float32, device=x.device)
+        io = _native.LayerNormIO()
+        io.M, io.S, io.eps = M, S, float(eps)
+        io.x, io.x_ld, io.y, io.y_ld = x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0)
+        io.gamma = weight.data_ptr() if weight is not None else None
+        io.beta = bias.data_ptr() if bias is not None else None
+        io.mean, io.rstd = mean.data_ptr(), rstd.data_ptr()
+        with torch.cuda.device(x.device):
+            _native.check(lib.macjd_layernorm_forward(ctypes.byref(io), _stream(x)), "macjd_layernorm_forward")
+        ctx.save_for_backward(x, mean, rstd, weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, mean, rstd, weight, bias = ctx.saved_tensors
+        mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]]
+        gx, gw, gb = torch.ops.aten.native_layer_norm_backward(gy.contiguous(), x.contiguous(), [x.shape[1]], mean, rstd,
+                                                               weight, bias, mask)
+        return gx, gw, gb, None
+
+
+def layer_norm(x, weight, bias, eps: float = 1e-5):
+    """F.layer_norm over the last dim of a 2-D float32 tensor: one HIP launch forward (torch's is a moments kernel
+    + a normalise kernel); backward is torch's native_layer_norm_backward on the saved mean / rstd."""
+    if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] <= 1024 and weight is not None and bias is not None:
+        return _LayerNormHip.apply(x, weight, bias, eps)
+    return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
 
 
 def linear(x, weight, bias=None):

@@ -396,6 +396,104 @@ def test_graphed_rollout_equals_eager_rollout():
             assert torch.equal(a, b), k
 
 
+def test_gru_sequence_kernel_strided_initial_state():
+    """h0 handed over as step 0 of a stored [B, T+1, J, H] tensor (batch stride (T+1) J H): no copy, same result."""
+    from macjd_amd import ops
+    B, T, J, H = 6, 9, 3, 64
+    g = torch.Generator().manual_seed(3)
+    gi = torch.randn(B, T, J, 3 * H, generator=g).to(DEV)
+    w_hh = (0.2 * torch.randn(3 * H, H, generator=g)).to(DEV)
+    b_hh = (0.1 * torch.randn(3 * H, generator=g)).to(DEV)
+    stored = torch.randn(B, T + 1, J, H, generator=g).to(DEV)
+    h0_view = stored[:, 0]
+    assert not h0_view.is_contiguous()
+    out = ops.gru_sequence(gi, w_hh, b_hh, h0_view)
+    ref = ops.gru_sequence_reference(gi, w_hh, b_hh, h0_view.contiguous())
+    np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), atol=TOL, rtol=0)
+
+
+def test_qhead_input_rows_kernel():
+    """[h, onehot(a), P] rows in one launch == the reference's full / one_hot / cat sequence (networks.py:160-172),
+    int32 and int64 indices, strided h, out-of-range index -> empty one-hot block."""
+    from macjd_amd import ops
+    n, H, A = 1003, 64, 9
+    g = torch.Generator().manual_seed(4)
+    wide = torch.randn(n, H + 7, generator=g).to(DEV)
+    h = wide[:, 3:3 + H]
+    P = torch.rand(n, 1, generator=g).to(DEV)
+    for dt in (torch.int64, torch.int32):
+        idx = torch.randint(0, A, (n, 1), generator=g).to(dt).to(DEV)
+        got = ops.qhead_input(h, idx, P, A)
+        want = torch.cat([h, torch.nn.functional.one_hot(idx.view(-1).long(), A).float(), P], dim=1)
+        assert torch.equal(got, want)
+    idx = torch.full((n,), A + 2, dtype=torch.int64, device=DEV)
+    assert float(ops.qhead_input(h, idx, P, A)[:, H:H + A].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("M,S", [(3232, 46), (7, 5), (513, 130), (64, 1024)])
+def test_layernorm_forward_kernel_and_backward(M, S):
+    """One-launch LayerNorm forward (saving mean / rstd) + torch's native backward == F.layer_norm under autograd."""
+    from macjd_amd import ops
+    g = torch.Generator().manual_seed(M + S)
+    x = (3.0 * torch.randn(M, S, generator=g) + 1.5).to(DEV).requires_grad_(True)
+    w = (1.0 + 0.3 * torch.randn(S, generator=g)).to(DEV).requires_grad_(True)
+    b = (0.2 * torch.randn(S, generator=g)).to(DEV).requires_grad_(True)
+    up = torch.randn(M, S, generator=g).to(DEV)
+    y = ops.layer_norm(x, w, b, 1e-5)
+    gx, gw, gb = torch.autograd.grad((y * up).sum(), [x, w, b])
+    y_ref = torch.nn.functional.layer_norm(x, (S,), w, b, 1e-5)
+    rx, rw, rb = torch.autograd.grad((y_ref * up).sum(), [x, w, b])
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y_ref.detach().cpu().numpy(), atol=2e-6, rtol=1e-6)
+    np.testing.assert_allclose(gx.cpu().numpy(), rx.cpu().numpy(), atol=2e-5, rtol=1e-5)
+    scale = max(1.0, float(rw.abs().max()))
+    np.testing.assert_allclose(gw.cpu().numpy(), rw.cpu().numpy(), atol=1e-5 * scale, rtol=1e-5)
+    np.testing.assert_allclose(gb.cpu().numpy(), rb.cpu().numpy(), atol=1e-5 * scale, rtol=1e-5)
+
+
+def test_mixer_merged_first_layer_equals_concatenated_form():
+    """QMixer on the flat-parameter views (no torch.cat, merged ReLU, strided b1 block, fused LayerNorm) ==
+    the same module evaluated through the plain concatenation path: Q_tot and every parameter gradient."""
+    from macjd_amd.core.mac import BasicMAC
+    from macjd_amd.core.qmix import QMixLearner
+    g, d = load("3j4r_h64")
+    args = _gpu_args(d)
+    with quiet():
+        mac = BasicMAC(d["S"], args)
+        learner = QMixLearner(mac, args)
+    mx = learner.eval_qmix_net
+    assert mx._merged_views is not None and learner.target_qmix_net._cat_cache is not None
+    gen = torch.Generator().manual_seed(8)
+    M = 777
+    q = torch.randn(M, 1, d["J"], generator=gen).to(DEV)
+    st = torch.randn(M, 1, mx.state_dim, generator=gen).to(DEV)
+    up = torch.randn(M, 1, 1, generator=gen).to(DEV)
+    params = list(mx.parameters())
+
+    def run():
+        for p in params:
+            p.grad = None
+        y = mx(q, st)
+        (y * up).sum().backward()
+        return y.detach().clone(), [p.grad.detach().clone() for p in params]
+
+    y_m, g_m = run()
+    views, mx._merged_views = mx._merged_views, None      # plain path: torch.cat of the four layers
+    try:
+        y_c, g_c = run()
+    finally:
+        mx._merged_views = views
+    np.testing.assert_allclose(y_m.cpu().numpy(), y_c.cpu().numpy(), atol=TOL, rtol=0)
+    for a, b in zip(g_m, g_c):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-5 * max(1.0, float(b.abs().max())), rtol=1e-5)
+    # the target copy answers from its cache, and the cache follows load_state_dict (the target sync)
+    tm = learner.target_qmix_net
+    with torch.no_grad():
+        for p in mx.parameters():
+            p.add_(0.01)
+        tm.load_state_dict(mx.state_dict())
+        np.testing.assert_allclose(tm(q, st).cpu().numpy(), mx(q, st).cpu().numpy(), atol=TOL, rtol=0)
+
+
 @pytest.mark.parametrize("J,Em,M", [(3, 64, 3168), (6, 64, 100), (2, 32, 7), (3, 96, 33)])
 def test_mixer_tail_kernel_forward_backward(J, Em, M):
     """Fused mixer tail (clamp / bmm / ELU / bmm) and its backward vs the stock-torch form, with inputs
