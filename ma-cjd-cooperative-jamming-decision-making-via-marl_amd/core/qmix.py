@@ -220,19 +220,41 @@ class QMixLearner:
         B, T1 = st["state"].shape[0], T + 1
         J, H = self.n_agents, self.args.rnn_hidden_dim
         rollout_hidden = self.mac.hidden_states
-        with torch.no_grad():
+
+        def targets():
             # [B,T+1,J,A]; the controllers' hidden states are left alone (the rollout owns them)
             target_q_all, eval_q_all = self._all_action_q_multi([self.target_mac, self.mac], st["obs"],
-                                                                keep_final_hidden=False)
-            self.mac.hidden_states = rollout_hidden
+                                                                keep_final_hidden=False, fork_from=origin)
             next_actions = eval_q_all.argmax(dim=3, keepdim=True)                      # qmix.py:138-143 (no mask)
             target_q_taken = torch.gather(target_q_all, 3, next_actions).squeeze(3)    # qmix.py:147
-            target_q_tot = self.target_qmix_net(target_q_taken, st["state"])           # [B,T+1,1], qmix.py:151
+            return self.target_qmix_net(target_q_taken, st["state"])                   # [B,T+1,1], qmix.py:151
+
+        # The no-grad target chain (both unrolls — a ~80 us latency-bound scan — all-action Q, argmax, target mixer)
+        # and the differentiable eval chain (Q-head on the STORED hidden states, eval mixer) are independent until the
+        # loss: on a HIP device the target chain runs on a side stream (fork / join by stream waits, also inside a
+        # captured graph) while this stream does the differentiable forward.  Autograd only ever sees this stream.
+        dev = st["state"].device
+        tstream = origin = None
+        if dev.type == "cuda":
+            origin = torch.cuda.current_stream(dev)
+            if getattr(self, "_target_stream", None) is None:
+                self._target_stream = torch.cuda.Stream(device=dev)
+            tstream, main = self._target_stream, torch.cuda.current_stream(dev)
+            tstream.wait_stream(main)                                                   # fork
+            with torch.cuda.stream(tstream), torch.no_grad():
+                target_q_tot = targets()
+        else:
+            with torch.no_grad():
+                target_q_tot = targets()
+        self.mac.hidden_states = rollout_hidden
         n = B * T1 * J
         q_taken = self.mac.agent.get_q_value_for_action(
             st["hidden_state"].view(n, H), st["actions_discrete"].view(n, 1), st["actions_continuous"].view(n, 1),
             validate=False).view(B, T1, J)                                              # qmix.py:161-184
         eval_q_tot = self.eval_qmix_net(q_taken, st["state"])                          # [B,T+1,1], qmix.py:187
+        if tstream is not None:
+            torch.cuda.current_stream(dev).wait_stream(tstream)                         # join
+            target_q_tot.record_stream(torch.cuda.current_stream(dev))
         # loss over eval steps 0..T-2 against targets built from target steps 1..T-1 (qmix.py:155,190-194)
         loss, eval_mean, target_mean = ops.td_loss_full(eval_q_tot, target_q_tot, st["reward"], st["terminated"],
                                                         st["filled"], self.args.gamma, T - 1, 1)
@@ -361,7 +383,7 @@ class QMixLearner:
         loss, ev, tg = self._g_out_a
         return self._pack_stats(loss, self._g_out_b, ev, tg, sync_stats)
 
-    def _all_action_q_multi(self, macs, obs, keep_final_hidden=True):
+    def _all_action_q_multi(self, macs, obs, keep_final_hidden=True, fork_from=None):
         """Q(s_t, a, P_a(s_t)) for every discrete action, [B, T, J, A] per controller; replaces the
         per-step / per-action unroll of qmix.py:217-280 (the discarded ``params`` tensor is not built).
         Everything but the recurrence is time-parallel: one GEMM each for fc1, the GRU input transform,
@@ -377,7 +399,9 @@ class QMixLearner:
             if getattr(self, "_side_stream", None) is None:
                 self._side_stream = torch.cuda.Stream(device=rows.device)
             side, main = self._side_stream, torch.cuda.current_stream(rows.device)
-            side.wait_stream(main)                                           # fork
+            # fork (from the caller's origin stream when this call itself runs on a forked stream: HIP graph
+            # capture wants every fork to hang off the capture's origin, not off another fork)
+            side.wait_stream(fork_from if fork_from is not None else main)
             with torch.cuda.stream(side):
                 params = [m.agent.actor_forward(rows) for m in macs]         # networks.py:127
         else:
