@@ -193,7 +193,7 @@ int macjd_gather_rows(const macjd_gather_io* io, void* hip_stream);
 
 /*
  * Input rows of the Q-head for the TAKEN action, out[n, :] = [h[n, 0..H-1], onehot_A(idx[n]), P[n]]  — the
- * torch.full / F.one_hot / torch.cat sequence of RNNAgent.get_q_value_for_action (reference core/networks.py:160-172)
+ * F.one_hot / torch.cat sequence of RNNAgent.get_q_value_for_action (reference core/networks.py:160-174)
  * as one launch.  idx outside [0, A) gives an all-zero one-hot block (the caller validates indices when asked to).
  */
 typedef struct macjd_qinput_io {
@@ -208,7 +208,7 @@ typedef struct macjd_qinput_io {
 int macjd_qhead_input(const macjd_qinput_io* io, void* hip_stream);
 
 /*
- * LayerNorm forward over the last dimension (QMixer.state_norm, reference core/networks.py:215,283):
+ * LayerNorm forward over the last dimension (QMixer.state_norm, reference core/networks.py:215,270):
  *   mean = sum(x)/S, var = sum((x-mean)^2)/S (biased, two-pass), rstd = rsqrt(var + eps), y = (x-mean) rstd gamma + beta.
  * mean / rstd [M] are saved for torch's native_layer_norm_backward.  S <= 1024.
  */

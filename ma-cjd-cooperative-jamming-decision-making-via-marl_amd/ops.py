@@ -488,7 +488,7 @@ def merged_linear(x, w_cat, b_cat, params):
 
 def qhead_input(h, idx, P, n_actions: int):
     """[h, onehot(idx), P] rows for the Q-head, [n, H + A + 1] float32 — one launch on a HIP device (the reference
-    builds it with torch.full / one_hot / cat, core/networks.py:160-172).  Not differentiable (its inputs are data)."""
+    builds it with F.one_hot / torch.cat, core/networks.py:160-174).  Not differentiable (its inputs are data)."""
     n, H = h.shape
     if not h.is_cuda:
         onehot = (idx.reshape(n, 1) == torch.arange(n_actions, device=idx.device, dtype=idx.dtype)).to(h.dtype)

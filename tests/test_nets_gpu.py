@@ -413,7 +413,7 @@ def test_gru_sequence_kernel_strided_initial_state():
 
 
 def test_qhead_input_rows_kernel():
-    """[h, onehot(a), P] rows in one launch == the reference's full / one_hot / cat sequence (networks.py:160-172),
+    """[h, onehot(a), P] rows in one launch == the reference's one_hot / cat sequence (networks.py:160-174),
     int32 and int64 indices, strided h, out-of-range index -> empty one-hot block."""
     from macjd_amd import ops
     n, H, A = 1003, 64, 9
