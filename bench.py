@@ -25,6 +25,12 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def per_env_table_bytes(J, R):
+    """Per-env scenario mode: each env-step also streams its env's SoA table column —
+    6R + 3J + JR float64 rows and JR flag bytes (include/macjd.h, macjd_step_io.pe_tables)."""
+    return 8 * (6 * R + 3 * J + J * R) + J * R
+
+
 def algorithmic_bytes_per_env_step(J, R, uniforms_supplied, info_outputs=True):
     """DESIGN.md section 'Algorithmic bytes': what one env-step must move through HBM.
     reads : T 4J + P 4J + step 4 (+ uniforms, counted as SURVEY.md 8(d) does, 4(R+J), when supplied)
@@ -83,7 +89,7 @@ def cpu_baseline(sc, E, seed, budget_s=12.0):
     return out
 
 
-def pmc_traffic(J, R, E):
+def pmc_traffic(J, R, E, per_env=False):
     """HBM bytes per env_step launch from the committed rocprofv3 PMC summary (profiles/), collected in
     separate --pmc passes and corrected as MI355X_MICROARCH.md prescribes; None when no matching run."""
     import glob
@@ -92,7 +98,7 @@ def pmc_traffic(J, R, E):
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("kernel", "").endswith(f"<{J},{R}>") and str(E) in d.get("runs", {}):
+        if d.get("kernel", "").endswith(f"<{J},{R},per-env>" if per_env else f"<{J},{R}>") and str(E) in d.get("runs", {}):
             return d["runs"][str(E)]["traffic_bytes_per_launch"], os.path.basename(f)
     return None, None
 
@@ -109,6 +115,8 @@ def main():
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--sweep", action="store_true", help="also print an E-sweep of the env kernel (stderr)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-env-scenarios", dest="per_env", action="store_true",
+                    help="every env gets its own randomised scenario (positions / threat / powers): tables streamed from HBM")
     ap.add_argument("--no-graphs", dest="no_graphs", action="store_true", help="eager launches (A/B against HIP graphs)")
     ap.add_argument("--no-gemm-tuning", dest="no_gemm_tuning", action="store_true",
                     help="library GEMMs with default heuristics (A/B against TunableOp)")
@@ -137,7 +145,12 @@ def main():
                 raise
         mode = ("train" if bench_mod is not None else "env") if mode == "auto" else mode
 
-    env = BatchedElectromagneticEnvironment(scenario=sc, batch_envs=E, device=dev, seed=42, env_offset=rank * E)
+    if args.per_env:
+        from macjd_amd.scenario import ScenarioBatch
+        batch = ScenarioBatch.randomized(ring_scenario_dict(J, R), E, seed=42, env_offset=rank * E)
+        env = BatchedElectromagneticEnvironment(scenario_batch=batch, device=dev, seed=42, env_offset=rank * E)
+    else:
+        env = BatchedElectromagneticEnvironment(scenario=sc, batch_envs=E, device=dev, seed=42, env_offset=rank * E)
     env.reset()
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     # synthetic actions, agent-major storage [J, E] (T ~ U{0..2R}, P ~ U[0,1))
@@ -174,26 +187,32 @@ def main():
 
     # ---- roofline of the env-step kernel: HIP events on the launch stream ----
     ms = env.time_step_kernel(T, P, iters=200)
-    B_step = algorithmic_bytes_per_env_step(J, R, uniforms_supplied=False)
+    B_step = algorithmic_bytes_per_env_step(J, R, uniforms_supplied=False) + (per_env_table_bytes(J, R) if args.per_env else 0)
     achieved = E * B_step / (ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(J, R, E)[0],
-                "traffic_source": pmc_traffic(J, R, E)[1],
-                "kernel": (f"env_step_slots_kernel<{J},{R}>" if E < (1 << 17) else f"env_step_kernel<{J},{R}>"), "us_per_launch": round(ms * 1e3, 3),
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(J, R, E, args.per_env)[0],
+                "traffic_source": pmc_traffic(J, R, E, args.per_env)[1],
+                "kernel": (f"env_step_kernel<{J},{R},per-env tables>" if args.per_env else
+                           f"env_step_slots_kernel<{J},{R}>" if E < (1 << 17) else f"env_step_kernel<{J},{R}>"),
+                "us_per_launch": round(ms * 1e3, 3),
                 "bytes_per_env_step": B_step, "envs_per_launch": E}
     # large-batch point of the same kernel family (2^22 envs): the HBM-bound asymptote, measured every run so the
     # launch-bound fraction at the benchmark's E is not mistaken for the kernel's streaming rate
     if rank == 0:
         Eb = 1 << 22
-        eb = BatchedElectromagneticEnvironment(scenario=sc, batch_envs=Eb, device=dev, seed=1)
+        if args.per_env:   # the 4096 compiled scenarios, cycled
+            eb = BatchedElectromagneticEnvironment(scenario_batch=batch.tile(Eb), device=dev, seed=1)
+        else:
+            eb = BatchedElectromagneticEnvironment(scenario=sc, batch_envs=Eb, device=dev, seed=1)
         Tb = torch.randint(0, 2 * R + 1, (J, Eb), generator=g, device=dev, dtype=torch.int32).t()
         Pb = torch.rand((J, Eb), generator=g, device=dev).t()
         eb.time_step_kernel(Tb, Pb, iters=3)
         mb = eb.time_step_kernel(Tb, Pb, iters=20)
         gb = Eb * B_step / (mb * 1e-3) / 1e9
         roofline["large_batch"] = {"envs_per_launch": Eb, "us_per_launch": round(mb * 1e3, 2), "achieved": round(gb, 1),
-                                   "frac": round(gb / HBM_PEAK_GBS, 4), "kernel": f"env_step_kernel<{J},{R}>",
-                                   "traffic": pmc_traffic(J, R, Eb)[0]}
+                                   "frac": round(gb / HBM_PEAK_GBS, 4),
+                                   "kernel": f"env_step_kernel<{J},{R}" + (",per-env tables>" if args.per_env else ">"),
+                                   "traffic": pmc_traffic(J, R, Eb, args.per_env)[0]}
         eb.close()
         del eb, Tb, Pb
     # ---- MFMA-bound kernel of the path: the actor's fused dense chain (exact-f32 v_mfma_f32_16x16x4_f32) ----
@@ -264,7 +283,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{J} jammers / {R} radars, batch_envs={E} per GPU, GRU hidden={args.hidden}",
+            "config": {"workload": f"{J} jammers / {R} radars, batch_envs={E} per GPU, GRU hidden={args.hidden}"
+                                   + (", per-env randomised scenarios" if args.per_env else ""),
                        "mode": mode, "per_gpu_env_steps_per_s": round(E * args.steps / dt, 1), **extra},
             "roofline": roofline,
         }

@@ -29,6 +29,7 @@ extern "C" {
 #endif
 
 #define MACJD_ABI_VERSION 2
+#define MACJD_PE_ROWS(R, J) (6 * (R) + 3 * (J) + (J) * (R))
 
 #define MACJD_OK          0
 #define MACJD_EINVAL     -1  /* bad argument (shape, NULL, stride)            */
@@ -126,6 +127,16 @@ typedef struct macjd_step_io {
     double*  prj64;      /* [E,J] contiguous: received jamming power of jammer j's action if it
                             was recorded in info['jammer_actions'] (environment.py:288-295),
                             else -1; may be NULL */
+    /* Per-env scenario tables, optional (radar / jammer positions, threat levels ... randomised per
+       env — the mode in which the static scenario parameters carry real HBM bytes).  pe_tables is float64
+       [MACJD_PE_ROWS(R,J), pe_stride] row-major: row t of env e at pe_tables[t * pe_stride + e] (consecutive envs are
+       consecutive lanes: coalesced).  Row order, same quantities as macjd_scenario_desc:
+         GaPs[R] | Pn[R] | D[R] | pd_no[R] | rd_pen[R] | gr[R] | pmin[J] | pmax[J] | gj[J] | denom[J*R] (j-major)
+       pe_flags is uint8 [J*R, pe_stride] (MACJD_JR_*).  NULL = every env uses the scenario handle's tables; the
+       handle still supplies R, J, episode_limit, the r_p bounds and the Pd constants. */
+    const double*  pe_tables;
+    const uint8_t* pe_flags;
+    int64_t        pe_stride;   /* >= n_envs */
     float*   r_dpj_sum;  /* [E,3] contiguous, optional: (r_d, r_p, r_j) of this step are ADDED to it — the
                             per-episode sums behind run_info['avg_r_d'|'avg_r_p'|'avg_r_j']
                             (runners/episode_runner.py:88-90,141-143) without a separate launch */

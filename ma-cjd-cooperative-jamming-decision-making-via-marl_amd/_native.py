@@ -46,7 +46,9 @@ class StepIO(ctypes.Structure):
         ("pd", ctypes.c_void_p), ("pd_se", ctypes.c_int64), ("pd_sx", ctypes.c_int64),
         ("snr_with", ctypes.c_void_p), ("sw_se", ctypes.c_int64), ("sw_sx", ctypes.c_int64),
         ("out64", ctypes.c_void_p), ("pd64", ctypes.c_void_p), ("snr64", ctypes.c_void_p),
-        ("prj64", ctypes.c_void_p), ("r_dpj_sum", ctypes.c_void_p),
+        ("prj64", ctypes.c_void_p),
+        ("pe_tables", ctypes.c_void_p), ("pe_flags", ctypes.c_void_p), ("pe_stride", ctypes.c_int64),
+        ("r_dpj_sum", ctypes.c_void_p),
     ]
 
 

@@ -70,27 +70,32 @@ __device__ __forceinline__ double draw_uniform(const macjd_step_io& io, int64_t 
     return (slot & 1) ? u53(r.v[2], r.v[3]) : u53(r.v[0], r.v[1]);
 }
 
-template <int JT, int RT>
+// PE = per-env scenario tables (io.pe_tables, SoA [row][env]): every table read becomes a load from this lane's
+// column of the SoA (row index static for the per-jammer / per-radar loops, data-dependent for the reads gathered by
+// the chosen target radar); the shared-table variant stages the gathered tables in LDS instead.
+template <int JT, int RT, bool PE>
 __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restrict__ tb, const macjd_step_io io) {
     constexpr int NJ = JT ? JT : MAXJ;
     constexpr int NR = RT ? RT : MAXR;
     const int J = JT ? JT : tb->J;
     const int R = RT ? RT : tb->R;
 
-    // ---- LDS staging of the tables gathered by per-lane target index ----
-    __shared__ double s_denom[NJ * NR];
-    __shared__ double s_D[NR], s_Pn[NR], s_gr[NR];
-    __shared__ uint8_t s_flags[NJ * NR];
-    for (int i = threadIdx.x; i < J * R; i += blockDim.x) {
-        s_denom[i] = tb->denom[i];
-        s_flags[i] = tb->flags[i];
+    // ---- LDS staging of the tables gathered by per-lane target index (shared-table variant) ----
+    __shared__ double s_denom[PE ? 1 : NJ * NR];
+    __shared__ double s_D[PE ? 1 : NR], s_Pn[PE ? 1 : NR], s_gr[PE ? 1 : NR];
+    __shared__ uint8_t s_flags[PE ? 1 : NJ * NR];
+    if (!PE) {
+        for (int i = threadIdx.x; i < J * R; i += blockDim.x) {
+            s_denom[i] = tb->denom[i];
+            s_flags[i] = tb->flags[i];
+        }
+        for (int i = threadIdx.x; i < R; i += blockDim.x) {
+            s_D[i] = tb->D[i];
+            s_Pn[i] = tb->Pn[i];
+            s_gr[i] = tb->gr[i];
+        }
+        __syncthreads();
     }
-    for (int i = threadIdx.x; i < R; i += blockDim.x) {
-        s_D[i] = tb->D[i];
-        s_Pn[i] = tb->Pn[i];
-        s_gr[i] = tb->gr[i];
-    }
-    __syncthreads();
 
     const double rp_min = tb->rp_min, rp_max = tb->rp_max;
     const double pdA = tb->pd_A, pdc1 = tb->pd_c1, pdden = tb->pd_denB;
@@ -101,6 +106,56 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
          e += (int64_t)gridDim.x * blockDim.x) {
         const int32_t step_before = io.step[e];
         const int32_t step_count = step_before + 1;  // environment.py:235
+
+        // table accessors: this env's SoA column (PE) or the shared tables
+        const double* __restrict__ pe = PE ? io.pe_tables + e : nullptr;
+        const int64_t ps = io.pe_stride;
+        // PE, compile-time sizes: every table value this env-step can touch is requested up front so that all the
+        // loads are in flight together — left at their use sites they sit behind branches and possibly-aliasing
+        // stores and arrive one memory latency at a time.  Static-index rows (per radar / per jammer) directly; the
+        // rows gathered by a jammer's chosen target radar after a pre-pass that decodes the J actions.
+        constexpr bool HOIST = PE && JT && RT;
+        double pv_r[HOIST ? 5 * NR : 1], pv_j[HOIST ? 3 * NJ : 1];
+        double gv_denom[HOIST ? NJ : 1], gv_gr[HOIST ? NJ : 1], gv_Pn[HOIST ? NJ : 1], gv_D[HOIST ? NJ : 1];
+        uint8_t gv_fl[HOIST ? NJ : 1];
+        if (HOIST) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+#pragma unroll
+                for (int r = 0; r < NR; ++r) pv_r[k * NR + r] = pe[(int64_t)(k * R + r) * ps];   // GaPs, Pn, D, pd_no, rd_pen
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) pv_j[k * NJ + j] = pe[(int64_t)(6 * R + k * J + j) * ps];   // pmin, pmax, gj
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int32_t Tj = io.T[e * io.T_se + (int64_t)j * io.T_sx];
+                const int tj = ((Tj >= 1) && (Tj <= 2 * R)) ? ((Tj + 1) / 2 - 1) : 0;
+                gv_denom[j] = pe[(int64_t)(6 * R + 3 * J + j * R + tj) * ps];
+                gv_gr[j] = pe[(int64_t)(5 * R + tj) * ps];
+                gv_Pn[j] = pe[(int64_t)(R + tj) * ps];
+                gv_D[j] = pe[(int64_t)(2 * R + tj) * ps];
+                gv_fl[j] = io.pe_flags[(int64_t)(j * R + tj) * ps + e];
+            }
+        }
+        auto t_GaPs = [&](int r) { return HOIST ? pv_r[0 * NR + r] : PE ? pe[(int64_t)(r) * ps] : tb->GaPs[r]; };
+        auto t_Pn = [&](int r) { return HOIST ? pv_r[1 * NR + r] : PE ? pe[(int64_t)(R + r) * ps] : tb->Pn[r]; };
+        auto t_D = [&](int r) { return HOIST ? pv_r[2 * NR + r] : PE ? pe[(int64_t)(2 * R + r) * ps] : tb->D[r]; };
+        auto t_pdno = [&](int r) { return HOIST ? pv_r[3 * NR + r] : PE ? pe[(int64_t)(3 * R + r) * ps] : tb->pd_no[r]; };
+        auto t_rdpen = [&](int r) { return HOIST ? pv_r[4 * NR + r] : PE ? pe[(int64_t)(4 * R + r) * ps] : tb->rd_pen[r]; };
+        auto t_pmin = [&](int j) { return HOIST ? pv_j[0 * NJ + j] : PE ? pe[(int64_t)(6 * R + j) * ps] : tb->pmin[j]; };
+        auto t_pmax = [&](int j) { return HOIST ? pv_j[1 * NJ + j] : PE ? pe[(int64_t)(6 * R + J + j) * ps] : tb->pmax[j]; };
+        auto t_gj = [&](int j) { return HOIST ? pv_j[2 * NJ + j] : PE ? pe[(int64_t)(6 * R + 2 * J + j) * ps] : tb->gj[j]; };
+        // gathered by jammer j's chosen target radar t
+        auto g_gr = [&](int j, int t) { return HOIST ? gv_gr[j] : PE ? pe[(int64_t)(5 * R + t) * ps] : s_gr[t]; };
+        auto g_Pn = [&](int j, int t) { return HOIST ? gv_Pn[j] : PE ? pe[(int64_t)(R + t) * ps] : s_Pn[t]; };
+        auto g_D = [&](int j, int t) { return HOIST ? gv_D[j] : PE ? pe[(int64_t)(2 * R + t) * ps] : s_D[t]; };
+        auto g_denom = [&](int j, int t) {
+            return HOIST ? gv_denom[j] : PE ? pe[(int64_t)(6 * R + 3 * J + j * R + t) * ps] : s_denom[j * R + t];
+        };
+        auto g_flags = [&](int j, int t) {
+            return HOIST ? gv_fl[j] : PE ? io.pe_flags[(int64_t)(j * R + t) * ps + e] : s_flags[j * R + t];
+        };
 
         double supp[NR];   // environment.py:241
         double prod[NR];   // environment.py:443-447
@@ -121,7 +176,7 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
             const int jtype = T % 2;  // 1 = suppression, 0 = deception (only read when is_jamming)
 
             // ---- power scale + r_p term, environment.py:271-277 ----
-            const double pmin = tb->pmin[j], pmax = tb->pmax[j];
+            const double pmin = t_pmin(j), pmax = t_pmax(j);
             const double power_range = pmax - pmin;
             double actual_d, norm;
             float actual_f = 0.0f;
@@ -141,17 +196,17 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
             r_p += rp_max + (rp_min - rp_max) * norm;  // environment.py:377-378
 
             // ---- received jamming power, environment.py:280-302, jammer.py:56-98 ----
-            const double denom = s_denom[j * R + target];
+            const double denom = g_denom(j, target);
             const bool recorded = is_jamming && (actual_d > 0.0) && (denom >= 0.0);
             double prj = 0.0;
             if (recorded && denom > 1e-18) {
-                const double grj = s_gr[target];
+                const double grj = g_gr(j, target);
                 if (arith32) {
-                    const float num = (actual_f * (float)tb->gj[j]) * (float)grj;
-                    prj = (s_flags[j * R + target] & MACJD_JR_WEAK_DENOM) ? (double)(num / (float)denom)
+                    const float num = (actual_f * (float)t_gj(j)) * (float)grj;
+                    prj = (g_flags(j, target) & MACJD_JR_WEAK_DENOM) ? (double)(num / (float)denom)
                                                                          : (double)num / denom;
                 } else {
-                    prj = (actual_d * tb->gj[j] * grj) / denom;
+                    prj = (actual_d * t_gj(j) * grj) / denom;
                 }
                 prj = (prj > 0.0) ? prj : 0.0;  // Python max(0.0, x)
             }
@@ -165,8 +220,8 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
 
             // ---- deception: false-target detection, environment.py:410-434 ----
             if (is_dec) {
-                const double Pn_t = s_Pn[target];
-                double snr_f = (Pn_t > 1e-18) ? (s_D[target] * prj) / Pn_t : 0.0;
+                const double Pn_t = g_Pn(j, target);
+                double snr_f = (Pn_t > 1e-18) ? (g_D(j, target) * prj) / Pn_t : 0.0;
                 snr_f = (snr_f > 0.0) ? snr_f : 0.0;
                 const double pd_f = det_prob(snr_f, pdA, pdc1, pdden);
                 const double u = draw_uniform(io, e, R + n_dec, (uint32_t)step_before);
@@ -185,9 +240,9 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             if (!RT && r >= R) break;
-            const double Pn = tb->Pn[r];
-            const double den = tb->D[r] * supp[r] + Pn;                       // :331
-            const double snr_with = (den > 1e-18) ? tb->GaPs[r] / den : 0.0;  // :332
+            const double Pn = t_Pn(r);
+            const double den = t_D(r) * supp[r] + Pn;                       // :331
+            const double snr_with = (den > 1e-18) ? t_GaPs(r) / den : 0.0;  // :332
             const double pd = det_prob(snr_with, pdA, pdc1, pdden);           // :337
             const double u = draw_uniform(io, e, r, (uint32_t)step_before);
             const bool detected = (u <= pd);                                   // :341
@@ -197,9 +252,9 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
             // read (saves R bytes of HBM reads per env-step); `track` is write-only here.
             const bool tracking = detected;
             io.track[e * io.k_se + (int64_t)r * io.k_sx] = tracking ? 1 : 0;
-            r_d += tracking ? tb->rd_pen[r] : 0.0;                             // :359-366 (post-update state)
+            r_d += tracking ? t_rdpen(r) : 0.0;                             // :359-366 (post-update state)
             if (supp_mask & (1u << r)) {                                       // :396-398
-                const double red = tb->pd_no[r] - pd;
+                const double red = t_pdno(r) - pd;
                 r_j += (red > 0.0) ? red : 0.0;
             }
             if (hit_mask & (1u << r)) r_j_dec += 1.0 - prod[r];               // :438-451
@@ -555,6 +610,8 @@ static int validate_io(const macjd_scenario* s, const macjd_step_io* io) {
     if ((io->pd && (io->pd_se == 0 && io->pd_sx == 0)) || (io->snr_with && (io->sw_se == 0 && io->sw_sx == 0)))
         return set_err(MACJD_EINVAL, "macjd_env_step: output strides are zero");
     if (io->k_se == 0 && io->k_sx == 0) return set_err(MACJD_EINVAL, "macjd_env_step: track strides are zero");
+    if (io->pe_tables && (!io->pe_flags || io->pe_stride < io->n_envs))
+        return set_err(MACJD_EINVAL, "macjd_env_step: per-env tables need pe_flags and pe_stride >= n_envs");
     return MACJD_OK;
 }
 
@@ -567,6 +624,8 @@ static int launch_step(const macjd_scenario* s, const macjd_step_io* io, hipStre
     bool slot_kernel = has_slot_kernel && E < (1 << 17);
     if (io->flags & MACJD_STEP_LANE_KERNEL) slot_kernel = false;
     if ((io->flags & MACJD_STEP_SLOT_KERNEL) && has_slot_kernel) slot_kernel = true;
+    const bool per_env = io->pe_tables != nullptr;
+    if (per_env) slot_kernel = false;   // per-env tables: lane-per-env kernel (each lane streams its own SoA column)
     if (slot_kernel) {  // one workgroup per 64 envs
         const dim3 g((unsigned)((E + 63) / 64));
 #define MACJD_SLOTS(JT, RT, NJW, NRW) \
@@ -585,7 +644,11 @@ static int launch_step(const macjd_scenario* s, const macjd_step_io* io, hipStre
         const int64_t cap = (block == 256) ? 256 * 8 : 256 * 16;
         if (grid > cap) grid = cap;
         const dim3 g((unsigned)grid), b(block);
-#define MACJD_LAUNCH(JT, RT) hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT>), g, b, 0, stream, s->dev, *io)
+#define MACJD_LAUNCH(JT, RT)                                                                                  \
+    do {                                                                                                      \
+        if (per_env) hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT, true>), g, b, 0, stream, s->dev, *io);  \
+        else hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT, false>), g, b, 0, stream, s->dev, *io);        \
+    } while (0)
         if (J == 3 && R == 4) MACJD_LAUNCH(3, 4);
         else if (J == 6 && R == 8) MACJD_LAUNCH(6, 8);
         else if (J == 12 && R == 16) MACJD_LAUNCH(12, 16);

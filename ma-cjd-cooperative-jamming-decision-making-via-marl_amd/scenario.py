@@ -330,6 +330,87 @@ class Scenario:
         return d, keep
 
 
+# Row order of the per-env SoA table (include/macjd.h, macjd_step_io.pe_tables)
+_PE_RADAR_ROWS = ("radar_GaPs", "radar_Pn", "radar_D", "radar_pd_no", "radar_rd_pen", "radar_gr")
+_PE_JAMMER_ROWS = ("jam_pmin", "jam_pmax", "jam_gj")
+
+
+def randomized_scenario_dict(base: dict, rng: np.random.Generator, position_jitter: float = 60.0,
+                             threat_jitter: float = 0.15, power_jitter: float = 0.2) -> dict:
+    """One random variation of a scenario dict in the reference's schema: radar and jammer
+    positions moved by N(0, position_jitter) metres per axis, threat levels by N(0, threat_jitter), radar peak
+    power ``pt`` and jammer ``power_max`` scaled by exp(N(0, power_jitter)).  Everything else is kept."""
+    import copy
+    d = copy.deepcopy(base)
+    for r in d["radars"]:
+        x, y = (float(v) for v in np.array(r["position"]).flatten()[:2])
+        r["position"] = [x + float(rng.normal(0.0, position_jitter)), y + float(rng.normal(0.0, position_jitter))]
+        r["threat_level"] = float(r.get("threat_level", 1.0) + rng.normal(0.0, threat_jitter))
+        r["pt"] = float(r["pt"] * np.exp(rng.normal(0.0, power_jitter)))
+    for j in d["jammers"]:
+        x, y = (float(v) for v in np.array(j["position"]).flatten()[:2])
+        j["position"] = [x + float(rng.normal(0.0, position_jitter)), y + float(rng.normal(0.0, position_jitter))]
+        j["power_max"] = float(j.get("power_max", 100.0) * np.exp(rng.normal(0.0, power_jitter)))
+    return d
+
+
+class ScenarioBatch:
+    """E scenarios of one shape (same R, J, episode limit, r_p bounds, Pd constants), compiled one by one with
+    :class:`Scenario` (so each env's tables are exactly what a single-scenario environment would use) and stacked
+    as the per-env SoA the step kernel streams: ``tables`` float64 [6R + 3J + JR, E], ``flags`` uint8 [JR, E],
+    plus the per-env observation vectors ``state_vectors`` f32 [E, S] and ``snr_no`` f64 [E, R]."""
+
+    def __init__(self, scenarios: List[Scenario]):
+        if not scenarios:
+            raise ValueError("ScenarioBatch needs at least one scenario")
+        s0 = scenarios[0]
+        for i, sc in enumerate(scenarios):
+            same = (sc.num_radars == s0.num_radars and sc.num_jammers == s0.num_jammers
+                    and sc.episode_limit == s0.episode_limit and sc.max_radar_types == s0.max_radar_types
+                    and sc.rp_min == s0.rp_min and sc.rp_max == s0.rp_max and sc.pd_consts == s0.pd_consts)
+            if not same:
+                raise ValueError(f"ScenarioBatch: scenario {i} differs from scenario 0 in shape / episode limit / "
+                                 f"r_p bounds / Pd constants (these are shared by the whole batch)")
+        self.scenarios = list(scenarios)
+        self.base = s0
+        self.n_envs = len(scenarios)
+        rows = []
+        for key in _PE_RADAR_ROWS + _PE_JAMMER_ROWS + ("jr_denom",):
+            rows.append(np.stack([np.asarray(sc.tables[key], dtype=np.float64).reshape(-1) for sc in scenarios], axis=1))
+        self.tables = np.ascontiguousarray(np.concatenate(rows, axis=0))                     # [rows, E]
+        self.flags = np.ascontiguousarray(np.stack([sc.tables["jr_flags"].reshape(-1) for sc in scenarios], axis=1)
+                                          .astype(np.uint8))                                  # [J*R, E]
+        self.state_vectors = np.stack([sc.state_vector() for sc in scenarios]).astype(np.float32)
+        self.snr_no = np.stack([sc.tables["radar_snr_no"] for sc in scenarios]).astype(np.float64)
+        R, J = s0.num_radars, s0.num_jammers
+        assert self.tables.shape == (6 * R + 3 * J + J * R, self.n_envs)
+
+    def tile(self, n_envs: int) -> "ScenarioBatch":
+        """A batch of ``n_envs`` envs that cycles through this batch's scenarios (env e runs scenario e mod E) —
+        for streaming-size measurements, where compiling millions of distinct scenarios on the host is pointless."""
+        reps = (int(n_envs) + self.n_envs - 1) // self.n_envs
+        out = object.__new__(ScenarioBatch)
+        out.scenarios = None                       # too many to keep per-env objects; ``base`` carries the shape
+        out.base, out.n_envs = self.base, int(n_envs)
+        out.tables = np.ascontiguousarray(np.tile(self.tables, (1, reps))[:, :n_envs])
+        out.flags = np.ascontiguousarray(np.tile(self.flags, (1, reps))[:, :n_envs])
+        out.state_vectors = np.ascontiguousarray(np.tile(self.state_vectors, (reps, 1))[:n_envs])
+        out.snr_no = np.ascontiguousarray(np.tile(self.snr_no, (reps, 1))[:n_envs])
+        return out
+
+    @classmethod
+    def randomized(cls, base_dict: dict, n_envs: int, seed: int = 0, config: Any = None, env_offset: int = 0,
+                   **jitter) -> "ScenarioBatch":
+        """``n_envs`` random variations of ``base_dict``; env e of the batch is variation number ``env_offset + e``
+        of the stream keyed by ``seed`` (shard-invariant: a rank's shard of a bigger batch is the same scenarios)."""
+        scs = []
+        for e in range(n_envs):
+            rng = np.random.default_rng([int(seed), int(env_offset) + e])
+            scs.append(Scenario.from_dict(randomized_scenario_dict(base_dict, rng, **jitter), config=config,
+                                          source=f"<randomized {seed}:{env_offset + e}>"))
+        return cls(scs)
+
+
 def ring_scenario_dict(n_jammers: int, n_radars: int) -> dict:
     """Build-authored ring scenarios in the reference's YAML schema for sizes the reference does not
     ship (it ships 2 jammers / 2 radars only, config/simulation_config.yaml).  Definition from

@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 from .. import _native
-from ..scenario import DEFAULT_SIM_CONFIG_PATH, Scenario
+from ..scenario import DEFAULT_SIM_CONFIG_PATH, Scenario, ScenarioBatch
 
 RADAR_STATE_SEARCH = "SEARCH"  # core/radar.py:5-7
 RADAR_STATE_TRACK = "TRACK"
@@ -64,7 +64,18 @@ class BatchedElectromagneticEnvironment:
 
     def __init__(self, config: Any = None, sim_config_path: str = DEFAULT_SIM_CONFIG_PATH,
                  batch_envs: Optional[int] = None, device=None, seed: Optional[int] = None,
-                 env_offset: int = 0, scenario: Optional[Scenario] = None, verbose: bool = False):
+                 env_offset: int = 0, scenario: Optional[Scenario] = None, verbose: bool = False,
+                 scenario_batch: Optional[ScenarioBatch] = None):
+        """``scenario_batch``: one scenario PER ENV (radar / jammer positions, threat levels, powers differing
+        between envs — SURVEY.md 8f-3); its tables live in HBM as an SoA that every step streams, and the
+        observation becomes a per-env [E, S] tensor (still constant in time)."""
+        self.scenario_batch = scenario_batch
+        if scenario_batch is not None:
+            scenario = scenario_batch.base
+            if batch_envs is None:
+                batch_envs = scenario_batch.n_envs
+            if int(batch_envs) != scenario_batch.n_envs:
+                raise ValueError(f"batch_envs ({batch_envs}) != scenarios in the batch ({scenario_batch.n_envs})")
         self.scenario = scenario if scenario is not None else Scenario.from_yaml(sim_config_path, config)
         sc = self.scenario
         self.num_jammers, self.num_radars = sc.num_jammers, sc.num_radars
@@ -95,6 +106,12 @@ class BatchedElectromagneticEnvironment:
         self._state_vec = torch.from_numpy(sc.state_vector()).to(dev)
         self._avail = torch.ones((1, 1, sc.n_actions), dtype=torch.int32, device=dev)
         self._snr_no = torch.from_numpy(sc.tables["radar_snr_no"]).to(dev)
+        self._pe_tables = self._pe_flags = self._state_vecs = None
+        if scenario_batch is not None:
+            self._pe_tables = torch.from_numpy(scenario_batch.tables).to(dev)       # f64 [rows, E]
+            self._pe_flags = torch.from_numpy(scenario_batch.flags).to(dev)         # u8  [J*R, E]
+            self._state_vecs = torch.from_numpy(scenario_batch.state_vectors).to(dev)   # f32 [E, S]
+            self._snr_no = torch.from_numpy(scenario_batch.snr_no).to(dev)          # f64 [E, R]
         self._io = _native.StepIO()
         self.kernel_flags = 0  # A/B hook: _native.STEP_LANE_KERNEL / STEP_SLOT_KERNEL force one kernel variant
         if verbose:
@@ -103,10 +120,14 @@ class BatchedElectromagneticEnvironment:
     # ---- reference-shaped getters, broadcast views (never materialised per env) ----
     def get_state(self) -> torch.Tensor:
         """f32 [E, S] expanded view of the static state vector (environment.py:479-510)."""
+        if self._state_vecs is not None:
+            return self._state_vecs
         return self._state_vec.unsqueeze(0).expand(self.batch_envs, -1)
 
     def get_obs(self) -> torch.Tensor:
         """f32 [E, J, S] expanded view: every agent observes the global state (environment.py:512-522)."""
+        if self._state_vecs is not None:
+            return self._state_vecs.unsqueeze(1).expand(-1, self.num_jammers, -1)
         return self._state_vec.view(1, 1, -1).expand(self.batch_envs, self.num_jammers, -1)
 
     def get_avail_actions(self) -> torch.Tensor:
@@ -191,6 +212,8 @@ class BatchedElectromagneticEnvironment:
         for k in ("out64", "pd64", "snr64", "prj64"):
             setattr(io, k, diag[k].data_ptr() if diag is not None else None)
         io.r_dpj_sum = rdpj_sum.data_ptr() if rdpj_sum is not None else None
+        if self._pe_tables is not None:
+            io.pe_tables, io.pe_flags, io.pe_stride = self._pe_tables.data_ptr(), self._pe_flags.data_ptr(), E
         # keep converted tensors alive until the launch has been enqueued (same-stream ordering
         # keeps their storage valid for the kernel: the caching allocator is stream-ordered)
         self._keep = (T, P, u, rew, ter, diag)

@@ -35,7 +35,7 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 REF = os.environ.get("MACJD_REFERENCE", "/root/reference")
 
 sys.path.insert(0, REPO)
-from macjd_amd.scenario import ring_scenario_dict  # build-authored scenario definitions (data)
+from macjd_amd.scenario import randomized_scenario_dict, ring_scenario_dict  # build-authored scenario definitions (data)
 
 
 def edge_scenario_dict():
@@ -68,7 +68,14 @@ def scenarios():
         "6j8r": ring_scenario_dict(6, 8),
         "12j16r": ring_scenario_dict(12, 16),
         "3j3r_edge": edge_scenario_dict(),
+        # per-env randomised scenarios: variations 0..2 of the 3j/4r ring, exactly the dicts
+        # ScenarioBatch.randomized(ring_scenario_dict(3, 4), n, seed=7) compiles for envs 0..2
+        **{f"3j4r_rand{k}": randomized_scenario_dict(ring_scenario_dict(3, 4), np.random.default_rng([7, k]))
+           for k in range(3)},
     }
+
+
+LIGHT = {"3j4r_rand0", "3j4r_rand1", "3j4r_rand2"}   # 100 steps, one seed per dtype mode
 
 
 @contextlib.contextmanager
@@ -104,12 +111,14 @@ def make_actions(rng, step, J, R):
     return T.astype(np.int64), P
 
 
-def gen_env(out_dir):
+def gen_env(out_dir, names=None):
     with reference_cwd():
         from simulation.environment import ElectromagneticEnvironment
         scs = scenarios()
         tmpdir = tempfile.mkdtemp(prefix="macjd_golden_")
         for name, sc in scs.items():
+            if names and name not in names:
+                continue
             path = os.path.join(tmpdir, name + ".yaml")
             with open(path, "w") as f:
                 yaml.safe_dump(sc, f)
@@ -124,9 +133,9 @@ def gen_env(out_dir):
             assert static["avail_actions"].dtype == np.int32
             rec = {"scenario_json": json.dumps(sc), "env_info_json": json.dumps(info0)}
             rec.update({"static_" + k: v for k, v in static.items()})
-            n_steps = 200
+            n_steps = 100 if name in LIGHT else 200
             for mode in ("f32", "f64"):
-                for seed in (42, 43, 44):
+                for seed in ((42,) if name in LIGHT else (42, 43, 44)):
                     rng = np.random.default_rng(1000 + seed)
                     np.random.seed(seed)
                     drawn = []
@@ -180,9 +189,10 @@ def gen_env(out_dir):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="all", choices=["env", "nets", "all"])
+    ap.add_argument("--names", default="", help="comma-separated env fixture names (default: all)")
     args = ap.parse_args()
     if args.only in ("env", "all"):
-        gen_env(HERE)
+        gen_env(HERE, set(args.names.split(",")) if args.names else None)
     if args.only in ("nets", "all"):
         try:
             from make_golden_nets import gen_nets

@@ -243,6 +243,75 @@ def test_reward_component_sums_accumulate_in_kernel():
         env.step(stage_T[0], stage_P[0], rdpj_sum=torch.zeros((E, 2), device="cuda"))
 
 
+RAND = ["3j4r_rand0", "3j4r_rand1", "3j4r_rand2"]
+
+
+@pytest.mark.parametrize("mode", ["f32", "f64"])
+def test_per_env_scenarios_follow_the_reference_traces(mode):
+    """Per-env scenario tables (SoA in HBM): env k of ONE batched environment runs fixture rand<k>'s scenario and
+    replays that fixture's own action / uniform trace; every env reproduces the reference (FSM bit-exact)."""
+    from macjd_amd.scenario import ScenarioBatch
+    from macjd_amd.simulation.environment import BatchedElectromagneticEnvironment
+    loaded = [load_scenario(n) for n in RAND]
+    batch = ScenarioBatch([sc for sc, _ in loaded])
+    E, R, J = 3, 4, 3
+    env = BatchedElectromagneticEnvironment(scenario_batch=batch, device="cuda:0")
+    assert env.batch_envs == E
+    np.testing.assert_array_equal(env.get_state().cpu().numpy(), np.stack([g["static_state"] for _, g in loaded]))
+    np.testing.assert_array_equal(env.get_obs().cpu().numpy()[:, 1], np.stack([g["static_state"] for _, g in loaded]))
+    pre = f"{mode}_s42_"
+    n = loaded[0][1][pre + "T"].shape[0]
+    diag = _diag(E, R, J)
+    st = lambda key: np.stack([g[pre + key] for _, g in loaded], axis=1)     # [steps, E, ...]
+    T, P, U = st("T"), st("P"), np.nan_to_num(st("u"), nan=2.0)
+    Td = torch.from_numpy(T).cuda()
+    Pd = torch.from_numpy(P.astype(np.float32) if mode == "f32" else P).cuda()
+    Ud = torch.from_numpy(U).cuda()
+    for t in range(n):
+        if loaded[0][1][pre + "reset_before"][t]:
+            env.reset()
+        _, term, info = env.step(Td[t], Pd[t], Ud[t], diag=diag)
+        np.testing.assert_array_equal(info["radar_tracking"].cpu().numpy(), st("track")[t], err_msg=f"step {t}")
+        np.testing.assert_array_equal(term.cpu().numpy(), st("terminated")[t])
+        ref = np.stack([st("reward")[t], st("r_d")[t], st("r_p")[t], st("r_j")[t]], axis=1)
+        np.testing.assert_allclose(diag["out64"].cpu().numpy(), ref, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(diag["pd64"].cpu().numpy(), st("pd")[t], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(diag["prj64"].cpu().numpy(), st("prj")[t], rtol=1e-14, atol=0)
+        np.testing.assert_allclose(info["snr_no_jamming"].cpu().numpy(), st("snr_no")[t], rtol=0, atol=0)
+
+
+def test_per_env_batch_equals_single_scenario_envs_and_oracle():
+    """E randomised scenarios in one launch == E single-scenario environments (bitwise, in-kernel Philox keyed by the
+    global env index) == the oracle run per env on that env's own scenario description."""
+    from macjd_amd.scenario import ScenarioBatch, ring_scenario_dict
+    from macjd_amd.simulation.environment import BatchedElectromagneticEnvironment
+    E, R, J = 40, 4, 3
+    batch = ScenarioBatch.randomized(ring_scenario_dict(3, 4), E, seed=3, env_offset=100)
+    env = BatchedElectromagneticEnvironment(scenario_batch=batch, device="cuda:0", seed=77, env_offset=100)
+    singles = [_env(sc, 1, seed=77, env_offset=100 + e) for e, sc in enumerate(batch.scenarios)]
+    oracles = [OracleEnv(sc, 1) for sc in batch.scenarios]
+    env.reset()
+    for s_ in singles:
+        s_.reset()
+    rng = np.random.default_rng(5)
+    diag = _diag(E, R, J)
+    for t in range(6):
+        T, P = random_actions(rng, E, J, R)
+        Td, Pd = torch.from_numpy(T).cuda(), torch.from_numpy(P).cuda()
+        rew, term, info = env.step(Td, Pd, diag=diag)
+        rews, tracks = [], []
+        for e, s_ in enumerate(singles):
+            r1, _, i1 = s_.step(Td[e:e + 1], Pd[e:e + 1])
+            rews.append(r1.clone()); tracks.append(i1["radar_tracking"].clone())
+            o = oracles[e].step(T[e:e + 1], P[e:e + 1], seed=77, env_offset=100 + e)
+            np.testing.assert_array_equal(info["radar_tracking"][e].cpu().numpy(), o["track"][0])
+            np.testing.assert_allclose(diag["out64"][e].cpu().numpy(), o["out64"][0], rtol=1e-9, atol=1e-12)
+        assert torch.equal(rew, torch.cat(rews)) and torch.equal(info["radar_tracking"], torch.cat(tracks))
+    assert float(rew.std()) > 0          # the scenarios really differ
+    with pytest.raises(ValueError):
+        BatchedElectromagneticEnvironment(scenario_batch=batch, batch_envs=E + 1, device="cuda:0")
+
+
 def test_bad_arguments_raise():
     sc, _ = load_scenario("3j4r")
     env = _env(sc, 8)

@@ -58,6 +58,39 @@ def test_env_trace(name, mode, seed):
         np.testing.assert_array_equal(o["reward"][0], np.float32(o["out64"][0, 0]))
 
 
+RAND = ["3j4r_rand0", "3j4r_rand1", "3j4r_rand2"]   # per-env randomised variations, light traces
+
+
+@pytest.mark.parametrize("name", RAND)
+@pytest.mark.parametrize("mode", ["f32", "f64"])
+def test_env_trace_randomised_scenarios(name, mode):
+    """The oracle on the reference's traces of the randomised 3j/4r variations (100 steps, seed 42)."""
+    test_env_trace(name, mode, 42)
+    test_static_tables_and_masks(name)
+
+
+def test_scenario_batch_is_the_fixture_scenarios():
+    """ScenarioBatch.randomized(ring 3j/4r, seed 7) env k == the scenario the reference ran for fixture rand<k>:
+    same dict, same compiled tables (SoA column k), same observation vector; shard-invariant by env_offset."""
+    from macjd_amd.scenario import ScenarioBatch, ring_scenario_dict
+    batch = ScenarioBatch.randomized(ring_scenario_dict(3, 4), 3, seed=7)
+    R, J = 4, 3
+    assert batch.tables.shape == (6 * R + 3 * J + J * R, 3) and batch.flags.shape == (J * R, 3)
+    for k, name in enumerate(RAND):
+        sc, g = load_scenario(name)
+        col = np.concatenate([sc.tables[key].reshape(-1) for key in
+                              ("radar_GaPs", "radar_Pn", "radar_D", "radar_pd_no", "radar_rd_pen", "radar_gr",
+                               "jam_pmin", "jam_pmax", "jam_gj", "jr_denom")])
+        np.testing.assert_array_equal(batch.tables[:, k], col)
+        np.testing.assert_array_equal(batch.flags[:, k], sc.tables["jr_flags"].reshape(-1))
+        np.testing.assert_array_equal(batch.state_vectors[k], g["static_state"])
+        np.testing.assert_array_equal(batch.snr_no[k], g["f64_s42_snr_no"][0])
+    shard = ScenarioBatch.randomized(ring_scenario_dict(3, 4), 2, seed=7, env_offset=1)
+    np.testing.assert_array_equal(shard.tables, batch.tables[:, 1:])
+    with pytest.raises(ValueError):
+        ScenarioBatch([load_scenario("3j4r")[0], load_scenario("6j8r")[0]])
+
+
 def test_f32_and_f64_modes_differ_in_reference():
     """Documents why both arithmetic modes exist: under NumPy 2 the reference's received power differs
     between np.float32 and python-float actions (float32 numerator, jammer.py:95)."""
