@@ -12,6 +12,8 @@ What is added (build flags, all optional):
                   episodes.  The learner then does ``episode_len // train_interval`` updates per ROLLOUT (the
                   reference does that many per episode; with ``batch_envs = 1`` the two coincide exactly).
   ``hip_graphs``  (default True on a HIP device with batch_envs > 1) replay rollouts / updates from HIP graphs.
+  ``randomize_scenarios`` / ``--randomize-scenarios`` (batched runs): every env trains on its own random variation
+                  of the scenario file (positions, threat levels, powers; ``scenario.ScenarioBatch``).
   ``--resume DIR`` restores agent, mixer, optimiser and ``trainer_state.json`` (env steps, episodes, epsilon
                   clock, learner step counters) — the reference saves the optimiser but never loads it and has
                   no resume path (``core/qmix.py:317-333``).
@@ -100,8 +102,16 @@ def build_components(args, sim_config_path):
     batch_envs = int(getattr(args, "batch_envs", 1) or 1)
     if batch_envs > 1:
         from .simulation.environment import BatchedElectromagneticEnvironment
+        off = int(getattr(args, "env_offset", 0))
+        batch = None
+        if getattr(args, "randomize_scenarios", False):   # every env its own variation of the scenario file
+            import yaml
+            from .scenario import ScenarioBatch
+            with open(sim_config_path) as f:
+                base = yaml.safe_load(f)
+            batch = ScenarioBatch.randomized(base, batch_envs, seed=args.seed, config=args, env_offset=off)
         env = BatchedElectromagneticEnvironment(args, sim_config_path, batch_envs=batch_envs, seed=args.seed,
-                                                env_offset=int(getattr(args, "env_offset", 0)), verbose=True)
+                                                env_offset=off, verbose=True, scenario_batch=batch)
     else:
         from .simulation.environment import ElectromagneticEnvironment
         env = ElectromagneticEnvironment(config=args, sim_config_path=sim_config_path)
@@ -302,6 +312,8 @@ def main(argv=None):
     parser.add_argument("--config-dir", type=str, default="config")
     parser.add_argument("--batch-envs", type=int, default=None)
     parser.add_argument("--resume", type=str, default=None)
+    parser.add_argument("--randomize-scenarios", action="store_true",
+                        help="batched runs: every env gets its own random variation of the scenario (per-env tables)")
     a = parser.parse_args(argv)
     config = load_config(config_name=a.config, config_dir=a.config_dir)
     config.config, config.env_config, config.device_request = a.config, a.env_config, a.device
@@ -309,6 +321,8 @@ def main(argv=None):
     if a.batch_envs is not None:
         config.batch_envs = a.batch_envs
     config.resume = a.resume
+    if a.randomize_scenarios:
+        config.randomize_scenarios = True
     return run(config)
 
 
