@@ -55,6 +55,12 @@ typedef struct macjd_qhead_io {
     int64_t* T_out64;                      /* optional chosen action, int64 */
     int64_t t32_se, t32_sj, t64_se, t64_sj;/* element strides over (env, agent) */
     float* P_out;       int64_t po_se, po_sj; /* optional chosen power = P_all[n, T] (mac.py:151-164) */
+    /* ---- Double-DQN helpers of the learner (reference core/qmix.py:138-147), contiguous [N] ----
+       argmax_out[n] = first arg-max of the UNMASKED Q-values (the reference applies no mask there);
+       q_gather_out[n] = Q[n, gather_idx[n]] (the target network's value of the eval network's choice). */
+    int64_t* argmax_out;
+    const int64_t* gather_idx;
+    float* q_gather_out;
 } macjd_qhead_io;
 
 int macjd_qhead_select(const macjd_qhead_io* io, void* hip_stream);

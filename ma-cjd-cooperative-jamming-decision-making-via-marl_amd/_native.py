@@ -70,6 +70,7 @@ class QheadIO(ctypes.Structure):
         ("T_out32", ctypes.c_void_p), ("T_out64", ctypes.c_void_p),
         ("t32_se", ctypes.c_int64), ("t32_sj", ctypes.c_int64), ("t64_se", ctypes.c_int64), ("t64_sj", ctypes.c_int64),
         ("P_out", ctypes.c_void_p), ("po_se", ctypes.c_int64), ("po_sj", ctypes.c_int64),
+        ("argmax_out", ctypes.c_void_p), ("gather_idx", ctypes.c_void_p), ("q_gather_out", ctypes.c_void_p),
     ]
 
 

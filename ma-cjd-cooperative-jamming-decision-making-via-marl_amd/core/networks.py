@@ -214,19 +214,26 @@ class QMixer(nn.Module):
         v_raw = ops.linear(h_v, self.V[2].weight, self.V[2].bias)
         return w1_raw, b1_raw, wf_raw, v_raw
 
-    def forward(self, agent_qs, states):
-        """Q_tot = ELU(q . clamp(W1(s),0,5) + clamp(b1(s),-5,5)) . clamp(Wf(s),0,5) + clamp(V(s),-5,5)
-        on the LayerNorm-ed state (networks.py:250-315; note clamp, not abs).  Output shape follows
-        the reference: [B, T, 1] for [B, T, J] inputs, [B, 1] for [B, J]."""
-        batch_size = agent_qs.size(0)
+    def hyper_outputs(self, states):
+        """The state-only half of the mixer: LayerNorm + the four hyper-networks -> (w1_raw, b1_raw, wf_raw, v_raw).
+        It does not depend on the agents' Q-values, so a caller may evaluate it early / on another stream and hand
+        the result to :meth:`forward` through ``hyper=``."""
         ln = self.state_norm
         s = ops.layer_norm(states.reshape(-1, self.state_dim), ln.weight, ln.bias, ln.eps)
-        q = agent_qs.reshape(-1, self.n_agents)
-        # clamp -> bmm -> ELU -> bmm (+ its backward) is one fused kernel on a HIP device (ops.mixer_tail)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(self.bf16_hyper and s.is_cuda)):
             raw = self._hyper_networks(s)
         if self.bf16_hyper and s.is_cuda:
             raw = tuple(r.float() for r in raw)
+        return raw
+
+    def forward(self, agent_qs, states, hyper=None):
+        """Q_tot = ELU(q . clamp(W1(s),0,5) + clamp(b1(s),-5,5)) . clamp(Wf(s),0,5) + clamp(V(s),-5,5)
+        on the LayerNorm-ed state (networks.py:250-315; note clamp, not abs).  Output shape follows
+        the reference: [B, T, 1] for [B, T, J] inputs, [B, 1] for [B, J]."""
+        batch_size = agent_qs.size(0)
+        raw = hyper if hyper is not None else self.hyper_outputs(states)
+        q = agent_qs.reshape(-1, self.n_agents)
+        # clamp -> bmm -> ELU -> bmm (+ its backward) is one fused kernel on a HIP device (ops.mixer_tail)
         y = ops.mixer_tail(q, *raw)
         q_tot = y.view(batch_size, -1, 1)
         if q_tot.shape[1] == 1:

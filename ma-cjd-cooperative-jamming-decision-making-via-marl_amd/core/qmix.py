@@ -223,11 +223,14 @@ class QMixLearner:
 
         def targets():
             # [B,T+1,J,A]; the controllers' hidden states are left alone (the rollout owns them)
-            target_q_all, eval_q_all = self._all_action_q_multi([self.target_mac, self.mac], st["obs"],
-                                                                keep_final_hidden=False, fork_from=origin)
-            next_actions = eval_q_all.argmax(dim=3, keepdim=True)                      # qmix.py:138-143 (no mask)
-            target_q_taken = torch.gather(target_q_all, 3, next_actions).squeeze(3)    # qmix.py:147
-            return self.target_qmix_net(target_q_taken, st["state"])                   # [B,T+1,1], qmix.py:151
+            # the target mixer's hyper-networks read only the state: they run on the actor side stream beside the
+            # scan, and only the mixer tail stays behind the target Q-values
+            # a* = argmax_a Q_eval (no mask, qmix.py:138-143) and Q_target(a*) (qmix.py:147) come straight out of the
+            # two Q-head launches: [B,T+1,J]
+            target_q_taken = self._all_action_q_multi(
+                [self.target_mac, self.mac], st["obs"], keep_final_hidden=False, fork_from=origin,
+                side_work=lambda: self.target_qmix_net.hyper_outputs(st["state"]), double_q=True)
+            return self.target_qmix_net(target_q_taken, st["state"], hyper=self._side_result)   # [B,T+1,1], qmix.py:151
 
         # The no-grad target chain (both unrolls — a ~80 us latency-bound scan — all-action Q, argmax, target mixer)
         # and the differentiable eval chain (Q-head on the STORED hidden states, eval mixer) are independent until the
@@ -383,7 +386,7 @@ class QMixLearner:
         loss, ev, tg = self._g_out_a
         return self._pack_stats(loss, self._g_out_b, ev, tg, sync_stats)
 
-    def _all_action_q_multi(self, macs, obs, keep_final_hidden=True, fork_from=None):
+    def _all_action_q_multi(self, macs, obs, keep_final_hidden=True, fork_from=None, side_work=None, double_q=False):
         """Q(s_t, a, P_a(s_t)) for every discrete action, [B, T, J, A] per controller; replaces the
         per-step / per-action unroll of qmix.py:217-280 (the discarded ``params`` tensor is not built).
         Everything but the recurrence is time-parallel: one GEMM each for fc1, the GRU input transform,
@@ -404,8 +407,11 @@ class QMixLearner:
             side.wait_stream(fork_from if fork_from is not None else main)
             with torch.cuda.stream(side):
                 params = [m.agent.actor_forward(rows) for m in macs]         # networks.py:127
+                # more scan-independent work for the side stream (it idles while the scan runs)
+                self._side_result = side_work() if side_work is not None else None
         else:
             params = [m.agent.actor_forward(rows) for m in macs]
+            self._side_result = side_work() if side_work is not None else None
         gis = [m.agent.gru_input_transform(rows).view(B, T, J, 3 * m.agent.rnn_hidden_dim) for m in macs]  # networks.py:100
         h_alls = ops.gru_sequence_multi(gis, [m.agent.rnn.weight_hh for m in macs],
                                         [m.agent.rnn.bias_hh for m in macs])  # h_0 = 0 (qmix.py:241)
@@ -419,8 +425,13 @@ class QMixLearner:
             bases.append(F.linear(h_all.reshape(B * T * J, H), l1.weight[:, :H], l1.bias))
         if side is not None:
             torch.cuda.current_stream(rows.device).wait_stream(side)        # join
-            for p in params:
+            for p in params + [t for t in (self._side_result or ()) if torch.is_tensor(t)]:
                 p.record_stream(torch.cuda.current_stream(rows.device))
+        if double_q:   # macs = [target, eval]: Q_target(h', argmax_a Q_eval) in two launches, [B, T, J]
+            heads = [(m.agent.fc2_q_head[0].weight, m.agent.fc2_q_head[2].weight, m.agent.fc2_q_head[2].bias) for m in macs]
+            a = macs[0].agent
+            return ops.qhead_double_q(bases[1], params[1], heads[1], bases[0], params[0], heads[0],
+                                      a.rnn_hidden_dim, a.n_actions).view(B, T, J)
         out = []
         for m, base, params_all in zip(macs, bases, params):
             a = m.agent

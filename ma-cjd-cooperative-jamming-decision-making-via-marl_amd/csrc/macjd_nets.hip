@@ -115,6 +115,26 @@ __global__ void __launch_bounds__(256) qhead_select_kernel(const macjd_qhead_io 
         acc[a] += b2;
         if (io.Q) io.Q[n * io.q_ld + a] = acc[a];
     }
+    if (io.argmax_out) {   // first maximum of the unmasked values (qmix.py:138-143)
+        int am = 0;
+        float aq = acc[0];
+#pragma unroll
+        for (int a = 1; a < AMAX; ++a) {
+            if (!AT && a >= A) break;
+            if (acc[a] > aq) { aq = acc[a]; am = a; }
+        }
+        io.argmax_out[n] = am;
+    }
+    if (io.gather_idx && io.q_gather_out) {   // qmix.py:147
+        const int64_t gi = io.gather_idx[n];
+        float gq = 0.0f;
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) {
+            if (!AT && a >= A) break;
+            gq = ((int64_t)a == gi) ? acc[a] : gq;
+        }
+        io.q_gather_out[n] = gq;
+    }
     if (!io.T_out32 && !io.T_out64) return;
 
     // ---- mask, greedy argmax (first maximum), epsilon-greedy; mac.py:142-146, action_selectors.py:34-62
@@ -170,7 +190,7 @@ extern "C" int macjd_qhead_select(const macjd_qhead_io* io, void* hip_stream) {
         return set_nets_err(MACJD_EINVAL, "macjd_qhead_select: bad n_rows / H / A / n_agents (A <= 64)");
     if (!io->base || !io->P_all || !io->W1 || !io->w2 || !io->b2)
         return set_nets_err(MACJD_EINVAL, "macjd_qhead_select: NULL input");
-    if (!io->Q && !io->T_out32 && !io->T_out64)
+    if (!io->Q && !io->T_out32 && !io->T_out64 && !io->argmax_out && !(io->gather_idx && io->q_gather_out))
         return set_nets_err(MACJD_EINVAL, "macjd_qhead_select: no output requested");
     if (io->avail && io->avail_elem_size != 4 && io->avail_elem_size != 8)
         return set_nets_err(MACJD_EINVAL, "macjd_qhead_select: avail_elem_size must be 4 or 8");

@@ -59,6 +59,36 @@ def qhead_all_actions(base, P_all, W1, w2, b2, H: int, A: int) -> torch.Tensor:
     return Q
 
 
+def qhead_double_q(base_eval, P_eval, head_eval, base_tgt, P_tgt, head_tgt, H: int, A: int) -> torch.Tensor:
+    """Double-DQN target values without materialising either [N, A] Q tensor (reference core/qmix.py:138-147):
+    a* = argmax_a Q_eval(h, a, P_a) (unmasked, as the reference), result [N] = Q_target(h', a*, P'_a*).
+    ``head_* = (W1, w2, b2)`` of each network's fc2_q_head.  Two launches on a HIP device."""
+    def q_all(base, P, head):
+        return qhead_all_actions(base, P, head[0], head[1], head[2], H, A)
+    if not base_eval.is_cuda:
+        idx = q_all(base_eval, P_eval, head_eval).argmax(dim=1, keepdim=True)
+        return torch.gather(q_all(base_tgt, P_tgt, head_tgt), 1, idx).squeeze(1)
+    lib = _native.load()
+    N = base_eval.shape[0]
+    dev = base_eval.device
+    idx = torch.empty(N, dtype=torch.int64, device=dev)
+    out = torch.empty(N, dtype=torch.float32, device=dev)
+    keep = []
+    for base, P, head, is_eval in ((base_eval, P_eval, head_eval, True), (base_tgt, P_tgt, head_tgt, False)):
+        base, P, W1 = _f32c(base.detach()), _f32c(P.detach()), _f32c(head[0].detach())
+        w2, b2 = head[1].detach().reshape(-1).contiguous(), head[2].detach().reshape(-1).contiguous()
+        keep += [base, P, W1, w2, b2]
+        io = _native.QheadIO()
+        _qhead_fill(io, base, P, W1, w2, b2, H, A, 1)
+        if is_eval:
+            io.argmax_out = idx.data_ptr()
+        else:
+            io.gather_idx, io.q_gather_out = idx.data_ptr(), out.data_ptr()
+        with torch.cuda.device(dev):
+            _native.check(lib.macjd_qhead_select(ctypes.byref(io), _stream(base)), "macjd_qhead_select")
+    return out
+
+
 def qhead_select(base, P_all, W1, w2, b2, H: int, A: int, n_agents: int, avail: Optional[torch.Tensor],
                  epsilon: float, greedy_only: bool, seed: int, counter: int, want_q: bool = False,
                  eps_dev: Optional[torch.Tensor] = None, counter_dev: Optional[torch.Tensor] = None,

@@ -71,6 +71,24 @@ def test_fused_qhead_vs_oracle(tag, N_envs):
     assert (avail.reshape(N, -1)[np.arange(N), got_T] == 1).all()
 
 
+def test_double_q_helper_equals_argmax_gather():
+    """Q_target(h', argmax_a Q_eval) from two Q-head launches == argmax + gather over the two full [N, A] Q tensors
+    (reference core/qmix.py:138-147; no availability mask there)."""
+    from macjd_amd import ops
+    N, H, A = 9696, 64, 9
+    gen = torch.Generator().manual_seed(11)
+    mk = lambda *sh, sc=1.0: (sc * torch.randn(*sh, generator=gen)).to(DEV)
+    be, bt = mk(N, H), mk(N, H)
+    Pe, Pt = torch.rand(N, A, generator=gen).to(DEV), torch.rand(N, A, generator=gen).to(DEV)
+    he = (mk(H, H + A + 1, sc=0.3), mk(1, H), mk(1, sc=0.1))
+    ht = (mk(H, H + A + 1, sc=0.3), mk(1, H), mk(1, sc=0.1))
+    got = ops.qhead_double_q(be, Pe, he, bt, Pt, ht, H, A)
+    qe = ops.qhead_all_actions(be, Pe, he[0], he[1], he[2], H, A)
+    qt = ops.qhead_all_actions(bt, Pt, ht[0], ht[1], ht[2], H, A)
+    want = torch.gather(qt, 1, qe.argmax(dim=1, keepdim=True)).squeeze(1)
+    assert torch.equal(got, want)
+
+
 def test_fused_selection_writes_into_caller_rows():
     """out_T32 / out_P: the select kernel stores the chosen actions into caller-provided [E,J,1] rows (the runner's
     staging tensors) — same values as the default agent-major scratch outputs."""
