@@ -218,46 +218,70 @@ class QMixLearner:
         Rows that the reference never evaluates (eval step T-1 and T, target step 0) cost ~2 % extra arithmetic,
         receive zero gradient and do not enter the loss: the result equals ``_forward_backward`` (tested)."""
         B, T1 = st["state"].shape[0], T + 1
-        J, H = self.n_agents, self.args.rnn_hidden_dim
-        rollout_hidden = self.mac.hidden_states
-
-        def targets():
-            # [B,T+1,J,A]; the controllers' hidden states are left alone (the rollout owns them)
-            # the target mixer's hyper-networks read only the state: they run on the actor side stream beside the
-            # scan, and only the mixer tail stays behind the target Q-values
-            # a* = argmax_a Q_eval (no mask, qmix.py:138-143) and Q_target(a*) (qmix.py:147) come straight out of the
-            # two Q-head launches: [B,T+1,J]
-            target_q_taken = self._all_action_q_multi(
-                [self.target_mac, self.mac], st["obs"], keep_final_hidden=False, fork_from=origin,
-                side_work=lambda: self.target_qmix_net.hyper_outputs(st["state"]), double_q=True)
-            return self.target_qmix_net(target_q_taken, st["state"], hyper=self._side_result)   # [B,T+1,1], qmix.py:151
-
-        # The no-grad target chain (both unrolls — a ~80 us latency-bound scan — all-action Q, argmax, target mixer)
-        # and the differentiable eval chain (Q-head on the STORED hidden states, eval mixer) are independent until the
-        # loss: on a HIP device the target chain runs on a side stream (fork / join by stream waits, also inside a
-        # captured graph) while this stream does the differentiable forward.  Autograd only ever sees this stream.
+        J, H, A = self.n_agents, self.args.rnn_hidden_dim, self.n_actions
+        n = B * T1 * J
         dev = st["state"].device
-        tstream = origin = None
+        macs = [self.target_mac, self.mac]
+        rows = st["obs"].reshape(n, -1)
+        heads = [(m.agent.fc2_q_head[0].weight, m.agent.fc2_q_head[2].weight, m.agent.fc2_q_head[2].bias) for m in macs]
+
+        # Two streams inside the (captured) update, balanced by hand from the kernel timeline
+        # (scripts/timeline_update.py):
+        #   side stream   (no grad) fc1 / GRU-input GEMMs of both controllers -> the fused scan (~85 us latency chain)
+        #                 -> Q-head base GEMMs
+        #   this stream   (no grad) the frozen actor chains -> (autograd) Q-head on the STORED hidden states + eval
+        #                 mixer -> (no grad) the target mixer's hyper-networks (they read only the state)
+        #   ONE join, then on this stream the two Double-DQN Q-head launches, the target mixer tail and the loss.
+        # Autograd only ever sees this stream.  The split took the step from 0.565 to 0.490 ms when it was introduced.
+        # Variants measured equal within run-to-run noise on one box (0.465-0.489 ms, 3 interleaved runs each): the
+        # Q-head / tail launches on the side stream behind two events, and a third stream for the actor /
+        # hyper-network work — so the simplest layout stays.  Forks taken from a forked stream crash
+        # hipStreamEndCapture (ROCm 7.2): every fork hangs off the capture's origin stream.
+        def scan_chain():
+            gis = [m.agent.gru_input_transform(rows).view(B, T1, J, 3 * H) for m in macs]      # networks.py:100
+            h_alls = ops.gru_sequence_multi(gis, [m.agent.rnn.weight_hh for m in macs],
+                                            [m.agent.rnn.bias_hh for m in macs])                 # h_0 = 0, qmix.py:241
+            return [F.linear(h.reshape(n, H), hd[0][:, :H], m.agent.fc2_q_head[0].bias)
+                    for m, h, hd in zip(macs, h_alls, heads)]
+
+        def actor_chains():
+            return [m.agent.actor_forward(rows) for m in macs]                                  # networks.py:127
+
+        def target_q_tot_of(bases, params, hyper):
+            # a* = argmax_a Q_eval (no mask, qmix.py:138-143), Q_target(a*) (qmix.py:147): two launches, [B,T+1,J]
+            tq = ops.qhead_double_q(bases[1], params[1], heads[1], bases[0], params[0], heads[0], H, A).view(B, T1, J)
+            return self.target_qmix_net(tq, st["state"], hyper=hyper)                          # [B,T+1,1], qmix.py:151
+
+        def eval_forward():
+            q_taken = self.mac.agent.get_q_value_for_action(
+                st["hidden_state"].view(n, H), st["actions_discrete"].view(n, 1), st["actions_continuous"].view(n, 1),
+                validate=False).view(B, T1, J)                                                  # qmix.py:161-184
+            return self.eval_qmix_net(q_taken, st["state"])                                    # [B,T+1,1], qmix.py:187
+
         if dev.type == "cuda":
             origin = torch.cuda.current_stream(dev)
             if getattr(self, "_target_stream", None) is None:
                 self._target_stream = torch.cuda.Stream(device=dev)
-            tstream, main = self._target_stream, torch.cuda.current_stream(dev)
-            tstream.wait_stream(main)                                                   # fork
-            with torch.cuda.stream(tstream), torch.no_grad():
-                target_q_tot = targets()
+            ts = self._target_stream
+            ts.wait_stream(origin)                                                              # fork
+            with torch.cuda.stream(ts), torch.no_grad():
+                bases = scan_chain()
+            with torch.no_grad():
+                params = actor_chains()
+            eval_q_tot = eval_forward()
+            with torch.no_grad():
+                hyper = self.target_qmix_net.hyper_outputs(st["state"])
+                origin.wait_stream(ts)                                                          # join
+                for t_ in bases:
+                    t_.record_stream(origin)
+                target_q_tot = target_q_tot_of(bases, params, hyper)
         else:
             with torch.no_grad():
-                target_q_tot = targets()
-        self.mac.hidden_states = rollout_hidden
-        n = B * T1 * J
-        q_taken = self.mac.agent.get_q_value_for_action(
-            st["hidden_state"].view(n, H), st["actions_discrete"].view(n, 1), st["actions_continuous"].view(n, 1),
-            validate=False).view(B, T1, J)                                              # qmix.py:161-184
-        eval_q_tot = self.eval_qmix_net(q_taken, st["state"])                          # [B,T+1,1], qmix.py:187
-        if tstream is not None:
-            torch.cuda.current_stream(dev).wait_stream(tstream)                         # join
-            target_q_tot.record_stream(torch.cuda.current_stream(dev))
+                target_q_tot = target_q_tot_of(scan_chain(), actor_chains(), self.target_qmix_net.hyper_outputs(st["state"]))
+            eval_q_tot = eval_forward()
+        return self._finish_update(st, T, eval_q_tot, target_q_tot)
+
+    def _finish_update(self, st, T, eval_q_tot, target_q_tot):
         # loss over eval steps 0..T-2 against targets built from target steps 1..T-1 (qmix.py:155,190-194)
         loss, eval_mean, target_mean = ops.td_loss_full(eval_q_tot, target_q_tot, st["reward"], st["terminated"],
                                                         st["filled"], self.args.gamma, T - 1, 1)
@@ -386,7 +410,7 @@ class QMixLearner:
         loss, ev, tg = self._g_out_a
         return self._pack_stats(loss, self._g_out_b, ev, tg, sync_stats)
 
-    def _all_action_q_multi(self, macs, obs, keep_final_hidden=True, fork_from=None, side_work=None, double_q=False):
+    def _all_action_q_multi(self, macs, obs, keep_final_hidden=True):
         """Q(s_t, a, P_a(s_t)) for every discrete action, [B, T, J, A] per controller; replaces the
         per-step / per-action unroll of qmix.py:217-280 (the discarded ``params`` tensor is not built).
         Everything but the recurrence is time-parallel: one GEMM each for fc1, the GRU input transform,
@@ -402,16 +426,11 @@ class QMixLearner:
             if getattr(self, "_side_stream", None) is None:
                 self._side_stream = torch.cuda.Stream(device=rows.device)
             side, main = self._side_stream, torch.cuda.current_stream(rows.device)
-            # fork (from the caller's origin stream when this call itself runs on a forked stream: HIP graph
-            # capture wants every fork to hang off the capture's origin, not off another fork)
-            side.wait_stream(fork_from if fork_from is not None else main)
+            side.wait_stream(main)                                           # fork
             with torch.cuda.stream(side):
                 params = [m.agent.actor_forward(rows) for m in macs]         # networks.py:127
-                # more scan-independent work for the side stream (it idles while the scan runs)
-                self._side_result = side_work() if side_work is not None else None
         else:
             params = [m.agent.actor_forward(rows) for m in macs]
-            self._side_result = side_work() if side_work is not None else None
         gis = [m.agent.gru_input_transform(rows).view(B, T, J, 3 * m.agent.rnn_hidden_dim) for m in macs]  # networks.py:100
         h_alls = ops.gru_sequence_multi(gis, [m.agent.rnn.weight_hh for m in macs],
                                         [m.agent.rnn.bias_hh for m in macs])  # h_0 = 0 (qmix.py:241)
@@ -425,13 +444,8 @@ class QMixLearner:
             bases.append(F.linear(h_all.reshape(B * T * J, H), l1.weight[:, :H], l1.bias))
         if side is not None:
             torch.cuda.current_stream(rows.device).wait_stream(side)        # join
-            for p in params + [t for t in (self._side_result or ()) if torch.is_tensor(t)]:
+            for p in params:
                 p.record_stream(torch.cuda.current_stream(rows.device))
-        if double_q:   # macs = [target, eval]: Q_target(h', argmax_a Q_eval) in two launches, [B, T, J]
-            heads = [(m.agent.fc2_q_head[0].weight, m.agent.fc2_q_head[2].weight, m.agent.fc2_q_head[2].bias) for m in macs]
-            a = macs[0].agent
-            return ops.qhead_double_q(bases[1], params[1], heads[1], bases[0], params[0], heads[0],
-                                      a.rnn_hidden_dim, a.n_actions).view(B, T, J)
         out = []
         for m, base, params_all in zip(macs, bases, params):
             a = m.agent

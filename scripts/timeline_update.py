@@ -1,0 +1,34 @@
+"""Summarise the kernel timeline of the LAST replayed train step in a rocprofv3 --kernel-trace CSV:
+per-queue busy time, the wall span of the step, and the longest gaps.  Usage:
+  rocprofv3 --kernel-trace -d out -o p -f csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-gemm-tuning
+  python scripts/timeline_update.py out/**/p_kernel_trace.csv"""
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")) for r in rows))
+# the timed region ends with the last gather_rows_kernel .. adam_bump pattern: take the last complete update
+idx = [i for i, e in enumerate(ev) if "gather_rows_kernel" in e[2]]
+bumps = [i for i, e in enumerate(ev) if "adam_bump_step_kernel" in e[2]]
+lo = idx[-2] if len(idx) >= 2 and idx[-1] > bumps[-1] else idx[-1]
+hi = [b for b in bumps if b > lo][0]
+step = ev[lo:hi + 1]
+t0 = step[0][0]
+print(f"update: {len(step)} kernels, span {(step[-1][1] - t0) / 1e3:.1f} us, sum of kernel time {sum(e[1] - e[0] for e in step) / 1e3:.1f} us")
+queues = {}
+for s, e, n, q in step:
+    queues.setdefault(q, []).append((s, e, n))
+for q, lst in queues.items():
+    print(f" queue {q}: {len(lst)} kernels, busy {sum(e - s for s, e, _ in lst) / 1e3:.1f} us, from {(lst[0][0] - t0) / 1e3:.1f} to {(lst[-1][1] - t0) / 1e3:.1f} us")
+# global coverage: time when NO kernel is running
+pts = sorted((s, e) for s, e, _, _ in step)
+idle, cur_end, gaps = 0, pts[0][0], []
+for s, e in pts:
+    if s > cur_end:
+        idle += s - cur_end
+        gaps.append((s - cur_end, cur_end - t0))
+    cur_end = max(cur_end, e)
+print(f" no kernel running: {idle / 1e3:.1f} us in {len(gaps)} gaps; largest: " + ", ".join(f"{g / 1e3:.1f}us@{at / 1e3:.0f}" for g, at in sorted(gaps, reverse=True)[:6]))
+print(" timeline (start us, dur us, queue, kernel):")
+for s, e, n, q in step:
+    print(f"  {(s - t0) / 1e3:7.1f} {(e - s) / 1e3:6.1f}  q{q}  {n[:70]}")
