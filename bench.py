@@ -106,8 +106,8 @@ def pmc_traffic(J, R, E, per_env=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--mode", default="auto", choices=["auto", "env", "rollout", "train"])
     ap.add_argument("--batch-envs", type=int, default=4096)
     ap.add_argument("--jammers", type=int, default=3)

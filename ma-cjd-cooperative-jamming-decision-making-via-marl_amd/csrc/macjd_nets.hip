@@ -18,6 +18,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <type_traits>
 
 #include "../../include/macjd.h"
 #include "../../include/macjd_nets.h"
@@ -238,12 +239,14 @@ extern "C" int macjd_qhead_select(const macjd_qhead_io* io, void* hip_stream) {
 //   * gi for step t+1 is loaded while step t computes; wave 0 stores h' (256-B coalesced rows).
 namespace macjd {
 
+// v_rcp_f32 / v_exp_f32 directly (1 ulp each): __frcp_rn is the CORRECTLY ROUNDED reciprocal and expands to the full
+// div_scale / div_fmas / div_fixup sequence, ~12 instructions per gate on the serial per-step chain
 __device__ __forceinline__ float gru_sigmoid(float x) {
-    return __frcp_rn(1.0f + __expf(-x));
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 __device__ __forceinline__ float gru_tanh(float x) {
     // tanh(x) = 1 - 2 / (exp(2x) + 1); saturates cleanly: exp -> inf gives 1, exp -> 0 gives -1
-    return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
 }
 
 template <int H, int NW>
@@ -251,7 +254,7 @@ __global__ void __launch_bounds__(64 * NW) gru_sequence_kernel(const macjd_gru_i
     constexpr int U = H / 64;    // hidden units per lane
     constexpr int KW = H / NW;   // K-slice per wave
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the readlane selects below stay SALU
     const int net = blockIdx.y;
     const int seq = blockIdx.x;  // b * J + j
     const int b = seq / io.J, j = seq - b * io.J;
@@ -276,7 +279,11 @@ __global__ void __launch_bounds__(64 * NW) gru_sequence_kernel(const macjd_gru_i
                 w[g][i][kk] = v.x; w[g][i][kk + 1] = v.y; w[g][i][kk + 2] = v.z; w[g][i][kk + 3] = v.w;
             }
         }
-    float bias[3][U], h[U], gcur[3][U], gnext[3][U], gnext2[3][U];   // gi ring: steps t, t+1, t+2
+    // gi ring of THREE register slots indexed at compile time (the t-loop is unrolled by 3): step t reads slot t % 3
+    // and requests row t + 2 into slot (t + 2) % 3.  No slot is ever copied: a rotation by register moves
+    // (cur = next; next = next2) needs the load issued in the same step to have landed, i.e. a full vmcnt(0) wait and
+    // one global-load latency on every step of the serial chain (that was 0.8 us / step; the chain itself is ~0.4).
+    float bias[3][U], h[U], ring[3][3][U];
 #pragma unroll
     for (int i = 0; i < U; ++i) {
         const int u = lane + 64 * i;
@@ -292,19 +299,21 @@ __global__ void __launch_bounds__(64 * NW) gru_sequence_kernel(const macjd_gru_i
         for (int g = 0; g < 3; ++g)
 #pragma unroll
             for (int i = 0; i < U; ++i) {
-                gcur[g][i] = r0[g * H + lane + 64 * i];
-                gnext[g][i] = r1[g * H + lane + 64 * i];
+                ring[0][g][i] = r0[g * H + lane + 64 * i];
+                ring[1][g][i] = r1[g * H + lane + 64 * i];
             }
     }
 
-    for (int t = 0; t < T; ++t) {
-        {   // prefetch the input transform TWO steps ahead (independent of the recurrence): one step (< 1 us) does
-            // not cover a global-load miss, and the wait for it sits on the critical path
+    // one step of the recurrence; SLOT = t % 3 is a compile-time constant
+    auto step = [&](auto slot_c, int t) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        constexpr int PRE = (SLOT + 2) % 3;
+        {   // request the input transform TWO steps ahead (independent of the recurrence)
             const float* rn = gi_row(t + 2 < T ? t + 2 : T - 1);
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
-                for (int i = 0; i < U; ++i) gnext2[g][i] = rn[g * H + lane + 64 * i];
+                for (int i = 0; i < U; ++i) ring[PRE][g][i] = rn[g * H + lane + 64 * i];
         }
         float acc[3][U];
 #pragma unroll
@@ -338,28 +347,30 @@ __global__ void __launch_bounds__(64 * NW) gru_sequence_kernel(const macjd_gru_i
             float gh[3];
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
-                float s = 0.0f;
+                float sacc = 0.0f;
 #pragma unroll
-                for (int ww = 0; ww < NW; ++ww) s += s_part[buf][ww][g][u];
-                gh[g] = s + bias[g][i];
+                for (int ww = 0; ww < NW; ++ww) sacc += s_part[buf][ww][g][u];
+                gh[g] = sacc + bias[g][i];
             }
             // sigmoid / tanh on the hardware exp2 + rcp units (~1 ulp each) instead of IEEE division + libm tanhf:
             // these sit on the strictly sequential per-step chain (about a third of its instructions); the 1e-5
             // tolerance on h after T = 100 steps is checked against the step-by-step float32 reference
-            const float r = gru_sigmoid(gcur[0][i] + gh[0]);
-            const float z = gru_sigmoid(gcur[1][i] + gh[1]);
-            const float n = gru_tanh(gcur[2][i] + r * gh[2]);
-            h[i] = (h[i] - n) * z + n;
+            const float r = gru_sigmoid(ring[SLOT][0][i] + gh[0]);
+            const float z = gru_sigmoid(ring[SLOT][1][i] + gh[1]);
+            const float nn = gru_tanh(ring[SLOT][2][i] + r * gh[2]);
+            h[i] = (h[i] - nn) * z + nn;
         }
         if (wave == 0) {
             float* orow = out + (((int64_t)b * T + t) * io.J + j) * H;
 #pragma unroll
             for (int i = 0; i < U; ++i) orow[lane + 64 * i] = h[i];
         }
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-            for (int i = 0; i < U; ++i) { gcur[g][i] = gnext[g][i]; gnext[g][i] = gnext2[g][i]; }
+    };
+
+    for (int t = 0; t < T; t += 3) {
+        step(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < T) step(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < T) step(std::integral_constant<int, 2>{}, t + 2);
     }
 }
 
