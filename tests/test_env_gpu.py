@@ -312,6 +312,32 @@ def test_per_env_batch_equals_single_scenario_envs_and_oracle():
         BatchedElectromagneticEnvironment(scenario_batch=batch, batch_envs=E + 1, device="cuda:0")
 
 
+@pytest.mark.parametrize("J,R", [(5, 7), (2, 2), (6, 8)])
+def test_per_env_tables_other_sizes_vs_oracle(J, R):
+    """Per-env tables on the generic kernel variant (5j/7r: run-time sizes, table reads at their use sites) and on
+    other compile-time sizes, against the oracle run per env on that env's own scenario; supplied uniforms."""
+    from macjd_amd.scenario import ScenarioBatch, ring_scenario_dict
+    from macjd_amd.simulation.environment import BatchedElectromagneticEnvironment
+    E = 33
+    batch = ScenarioBatch.randomized(ring_scenario_dict(J, R), E, seed=J * 100 + R)
+    env = BatchedElectromagneticEnvironment(scenario_batch=batch, device="cuda:0")
+    oracles = [OracleEnv(sc, 1) for sc in batch.scenarios]
+    env.reset()
+    rng = np.random.default_rng(J + R)
+    diag = _diag(E, R, J)
+    for t in range(4):
+        T, P = random_actions(rng, E, J, R)
+        u = rng.random((E, R + J))
+        rew, term, info = env.step(torch.from_numpy(T).cuda(), torch.from_numpy(P).cuda(), torch.from_numpy(u).cuda(),
+                                   diag=diag)
+        for e in range(E):
+            o = oracles[e].step(T[e:e + 1], P[e:e + 1], u=u[e:e + 1])
+            np.testing.assert_array_equal(info["radar_tracking"][e].cpu().numpy(), o["track"][0])
+            np.testing.assert_allclose(diag["out64"][e].cpu().numpy(), o["out64"][0], rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(diag["pd64"][e].cpu().numpy(), o["pd64"][0], rtol=1e-12, atol=0)
+            np.testing.assert_allclose(diag["prj64"][e].cpu().numpy(), o["prj64"][0], rtol=1e-14, atol=0)
+
+
 def test_bad_arguments_raise():
     sc, _ = load_scenario("3j4r")
     env = _env(sc, 8)
