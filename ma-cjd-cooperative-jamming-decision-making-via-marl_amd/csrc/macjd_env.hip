@@ -62,8 +62,9 @@ __device__ __forceinline__ double det_prob(double snr, double A, double c1, doub
     return (fabs(denB) < 1e-9) ? 0.0 : p;
 }
 
+template <bool PHILOX_ONLY = false>
 __device__ __forceinline__ double draw_uniform(const macjd_step_io& io, int64_t e, int slot, uint32_t step_before) {
-    if (io.u) return io.u[e * io.u_se + (int64_t)slot * io.u_sx];
+    if (!PHILOX_ONLY && io.u) return io.u[e * io.u_se + (int64_t)slot * io.u_sx];
     const uint64_t genv = (uint64_t)(io.env_offset + e);
     const Philox4 r = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), step_before, (uint32_t)(slot >> 1),
                                     (uint32_t)io.seed, (uint32_t)(io.seed >> 32));
@@ -73,7 +74,12 @@ __device__ __forceinline__ double draw_uniform(const macjd_step_io& io, int64_t 
 // PE = per-env scenario tables (io.pe_tables, SoA [row][env]): every table read becomes a load from this lane's
 // column of the SoA (row index static for the per-jammer / per-radar loops, data-dependent for the reads gathered by
 // the chosen target radar); the shared-table variant stages the gathered tables in LDS instead.
-template <int JT, int RT, bool PE>
+// FAST = the production configuration fixed at compile time: uniforms from Philox (io.u == NULL), float32 actions with
+// the reference's float32 power arithmetic (io.P32, no MACJD_STEP_ARITH_F64), no float64 diagnostics.  At streaming
+// sizes the kernel is VALU-issue bound (PMC: ~1670 VALU instructions per 64-env iteration, VALU busy 73 % of the
+// kernel); the run-time mode tests cost ~50 uniform branches and, through the extra live pointers, ~400 SGPR spill
+// instructions (v_writelane / v_readlane) per iteration.
+template <int JT, int RT, bool PE, bool FAST>
 __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restrict__ tb, const macjd_step_io io) {
     constexpr int NJ = JT ? JT : MAXJ;
     constexpr int NR = RT ? RT : MAXR;
@@ -100,7 +106,7 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
     const double rp_min = tb->rp_min, rp_max = tb->rp_max;
     const double pdA = tb->pd_A, pdc1 = tb->pd_c1, pdden = tb->pd_denB;
     const int32_t episode_limit = tb->episode_limit;
-    const bool arith32 = (io.P32 != nullptr) && !(io.flags & MACJD_STEP_ARITH_F64);
+    const bool arith32 = FAST ? true : ((io.P32 != nullptr) && !(io.flags & MACJD_STEP_ARITH_F64));
 
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < io.n_envs;
          e += (int64_t)gridDim.x * blockDim.x) {
@@ -210,7 +216,7 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
                 }
                 prj = (prj > 0.0) ? prj : 0.0;  // Python max(0.0, x)
             }
-            if (io.prj64) io.prj64[e * J + j] = recorded ? prj : -1.0;
+            if (!FAST && io.prj64) io.prj64[e * J + j] = recorded ? prj : -1.0;
 
             const bool is_sup = recorded && (jtype == 1);
             const bool is_dec = recorded && (jtype == 0);
@@ -224,7 +230,7 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
                 double snr_f = (Pn_t > 1e-18) ? (g_D(j, target) * prj) / Pn_t : 0.0;
                 snr_f = (snr_f > 0.0) ? snr_f : 0.0;
                 const double pd_f = det_prob(snr_f, pdA, pdc1, pdden);
-                const double u = draw_uniform(io, e, R + n_dec, (uint32_t)step_before);
+                const double u = draw_uniform<FAST>(io, e, R + n_dec, (uint32_t)step_before);
                 ++n_dec;
                 if (u <= pd_f) {
                     const double safe = pd_f < 0.999999 ? pd_f : 0.999999;  // environment.py:446
@@ -244,7 +250,7 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
             const double den = t_D(r) * supp[r] + Pn;                       // :331
             const double snr_with = (den > 1e-18) ? t_GaPs(r) / den : 0.0;  // :332
             const double pd = det_prob(snr_with, pdA, pdc1, pdden);           // :337
-            const double u = draw_uniform(io, e, r, (uint32_t)step_before);
+            const double u = draw_uniform<FAST>(io, e, r, (uint32_t)step_before);
             const bool detected = (u <= pd);                                   // :341
             // radar.py:102-117: SEARCH & detected -> TRACK, SEARCH & !detected -> SEARCH,
             // TRACK & !detected -> SEARCH, TRACK & detected -> TRACK.  The next state therefore
@@ -261,8 +267,8 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
             const double snr_rep = (snr_with > 0.0) ? snr_with : 0.0;         // :333
             if (io.pd) io.pd[e * io.pd_se + (int64_t)r * io.pd_sx] = (float)pd;
             if (io.snr_with) io.snr_with[e * io.sw_se + (int64_t)r * io.sw_sx] = (float)snr_rep;
-            if (io.pd64) io.pd64[e * R + r] = pd;
-            if (io.snr64) io.snr64[e * R + r] = snr_rep;
+            if (!FAST && io.pd64) io.pd64[e * R + r] = pd;
+            if (!FAST && io.snr64) io.snr64[e * R + r] = snr_rep;
         }
         r_j += r_j_dec;                          // :454
         const double reward = r_d + r_p + r_j;  // :457
@@ -280,7 +286,7 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
             io.r_dpj_sum[e * 3 + 1] += (float)r_p;
             io.r_dpj_sum[e * 3 + 2] += (float)r_j;
         }
-        if (io.out64) {
+        if (!FAST && io.out64) {
             io.out64[e * 4 + 0] = reward;
             io.out64[e * 4 + 1] = r_d;
             io.out64[e * 4 + 2] = r_p;
@@ -644,16 +650,24 @@ static int launch_step(const macjd_scenario* s, const macjd_step_io* io, hipStre
         const int64_t cap = (block == 256) ? 256 * 8 : 256 * 16;
         if (grid > cap) grid = cap;
         const dim3 g((unsigned)grid), b(block);
-#define MACJD_LAUNCH(JT, RT)                                                                                  \
-    do {                                                                                                      \
-        if (per_env) hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT, true>), g, b, 0, stream, s->dev, *io);  \
-        else hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT, false>), g, b, 0, stream, s->dev, *io);        \
+        // production configuration (Philox uniforms, float32 actions / power arithmetic, no float64 diagnostics)
+        const bool fast = !io->u && io->P32 && !(io->flags & MACJD_STEP_ARITH_F64) && !io->out64 && !io->pd64 &&
+                          !io->snr64 && !io->prj64;
+#define MACJD_LAUNCH(JT, RT)                                                                                          \
+    do {                                                                                                              \
+        if (per_env && fast) hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT, true, true>), g, b, 0, stream, s->dev, *io);       \
+        else if (per_env) hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT, true, false>), g, b, 0, stream, s->dev, *io);         \
+        else if (fast) hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT, false, true>), g, b, 0, stream, s->dev, *io);            \
+        else hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT, false, false>), g, b, 0, stream, s->dev, *io);                     \
     } while (0)
         if (J == 3 && R == 4) MACJD_LAUNCH(3, 4);
         else if (J == 6 && R == 8) MACJD_LAUNCH(6, 8);
         else if (J == 12 && R == 16) MACJD_LAUNCH(12, 16);
         else if (J == 2 && R == 2) MACJD_LAUNCH(2, 2);
-        else MACJD_LAUNCH(0, 0);
+        else {   // generic sizes: one (non-FAST) variant per table mode
+            if (per_env) hipLaunchKernelGGL((macjd::env_step_kernel<0, 0, true, false>), g, b, 0, stream, s->dev, *io);
+            else hipLaunchKernelGGL((macjd::env_step_kernel<0, 0, false, false>), g, b, 0, stream, s->dev, *io);
+        }
 #undef MACJD_LAUNCH
     }
     hipError_t err = hipGetLastError();

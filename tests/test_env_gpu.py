@@ -338,6 +338,38 @@ def test_per_env_tables_other_sizes_vs_oracle(J, R):
             np.testing.assert_allclose(diag["prj64"][e].cpu().numpy(), o["prj64"][0], rtol=1e-14, atol=0)
 
 
+@pytest.mark.parametrize("per_env", [False, True])
+@pytest.mark.parametrize("J,R", [(3, 4), (6, 8), (12, 16), (2, 2)])
+def test_fast_kernel_variant_equals_general_variant(J, R, per_env):
+    """The compile-time production variant of the lane kernel (Philox uniforms, float32 actions, no float64
+    diagnostics) == the general variant (selected here by asking for the diagnostics), bitwise, shared and per-env
+    tables."""
+    from macjd_amd import _native
+    from macjd_amd.scenario import Scenario, ScenarioBatch, ring_scenario_dict
+    from macjd_amd.simulation.environment import BatchedElectromagneticEnvironment
+    E = 300
+    base = ring_scenario_dict(J, R)
+    if per_env:
+        batch = ScenarioBatch.randomized(base, 25, seed=9).tile(E)
+        mk = lambda: BatchedElectromagneticEnvironment(scenario_batch=batch, device="cuda:0", seed=5, env_offset=64)
+    else:
+        sc = Scenario.from_dict(base)
+        mk = lambda: _env(sc, E, seed=5, env_offset=64)
+    fast, general = mk(), mk()
+    fast.kernel_flags = general.kernel_flags = _native.STEP_LANE_KERNEL
+    fast.reset(); general.reset()
+    rng = np.random.default_rng(R)
+    diag = _diag(E, R, J)
+    for t in range(5):
+        T, P = random_actions(rng, E, J, R)
+        Td, Pd = torch.from_numpy(T).cuda(), torch.from_numpy(P).cuda()
+        r1, t1, i1 = fast.step(Td, Pd)
+        r2, t2, i2 = general.step(Td, Pd, diag=diag)
+        assert torch.equal(r1, r2) and torch.equal(t1, t2)
+        for k in ("r_d", "r_p", "r_j", "radar_tracking", "radar_pds", "snr_with_jamming"):
+            assert torch.equal(i1[k], i2[k]), k
+
+
 def test_bad_arguments_raise():
     sc, _ = load_scenario("3j4r")
     env = _env(sc, 8)
