@@ -132,6 +132,8 @@ def main():
     from macjd_amd.scenario import Scenario, ring_scenario_dict
     from macjd_amd.simulation.environment import BatchedElectromagneticEnvironment
 
+    if os.environ.get("MACJD_PE_TILED", "1") == "0":   # A/B hook: plain SoA per-env tables
+        BatchedElectromagneticEnvironment.pe_tiled = False
     J, R, E = args.jammers, args.radars, args.batch_envs
     sc = Scenario.from_dict(ring_scenario_dict(J, R))
     dev = torch.device("cuda", local)

@@ -137,6 +137,13 @@ typedef struct macjd_step_io {
     const double*  pe_tables;
     const uint8_t* pe_flags;
     int64_t        pe_stride;   /* >= n_envs */
+    /* pe_tile > 0 selects the tiled (AoSoA) form of the same tables instead: envs are grouped in tiles of pe_tile
+       consecutive envs and a tile's rows are contiguous — row t of env e at
+       pe_tables[((e / pe_tile) * MACJD_PE_ROWS + t) * pe_tile + e % pe_tile] (flags alike with J*R rows) — so a
+       workgroup that handles pe_tile consecutive envs reads ONE contiguous block per step instead of 6R+3J+JR
+       streams pe_stride apart.  pe_stride is ignored then; the last tile is padded. */
+    int32_t        pe_tile;
+    int32_t        reserved_pe;
     float*   r_dpj_sum;  /* [E,3] contiguous, optional: (r_d, r_p, r_j) of this step are ADDED to it — the
                             per-episode sums behind run_info['avg_r_d'|'avg_r_p'|'avg_r_j']
                             (runners/episode_runner.py:88-90,141-143) without a separate launch */

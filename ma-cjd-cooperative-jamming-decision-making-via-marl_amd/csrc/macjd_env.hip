@@ -114,8 +114,12 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
         const int32_t step_count = step_before + 1;  // environment.py:235
 
         // table accessors: this env's SoA column (PE) or the shared tables
-        const double* __restrict__ pe = PE ? io.pe_tables + e : nullptr;
-        const int64_t ps = io.pe_stride;
+        // this env's column of the per-env tables: plain SoA (row stride pe_stride) or tiled (row stride = tile width)
+        const int64_t ps = (PE && io.pe_tile > 0) ? (int64_t)io.pe_tile : io.pe_stride;
+        const int64_t pe_tile_idx = (PE && io.pe_tile > 0) ? e / io.pe_tile : 0;
+        const int64_t pe_col = (PE && io.pe_tile > 0) ? e - pe_tile_idx * io.pe_tile : e;
+        const double* __restrict__ pe = PE ? io.pe_tables + pe_tile_idx * (6 * R + 3 * J + J * R) * ps + pe_col : nullptr;
+        const uint8_t* __restrict__ pf = PE ? io.pe_flags + pe_tile_idx * (J * R) * ps + pe_col : nullptr;
         // PE, compile-time sizes: every table value this env-step can touch is requested up front so that all the
         // loads are in flight together — left at their use sites they sit behind branches and possibly-aliasing
         // stores and arrive one memory latency at a time.  Static-index rows (per radar / per jammer) directly; the
@@ -141,7 +145,7 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
                 gv_gr[j] = pe[(int64_t)(5 * R + tj) * ps];
                 gv_Pn[j] = pe[(int64_t)(R + tj) * ps];
                 gv_D[j] = pe[(int64_t)(2 * R + tj) * ps];
-                gv_fl[j] = io.pe_flags[(int64_t)(j * R + tj) * ps + e];
+                gv_fl[j] = pf[(int64_t)(j * R + tj) * ps];
             }
         }
         auto t_GaPs = [&](int r) { return HOIST ? pv_r[0 * NR + r] : PE ? pe[(int64_t)(r) * ps] : tb->GaPs[r]; };
@@ -160,7 +164,7 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
             return HOIST ? gv_denom[j] : PE ? pe[(int64_t)(6 * R + 3 * J + j * R + t) * ps] : s_denom[j * R + t];
         };
         auto g_flags = [&](int j, int t) {
-            return HOIST ? gv_fl[j] : PE ? io.pe_flags[(int64_t)(j * R + t) * ps + e] : s_flags[j * R + t];
+            return HOIST ? gv_fl[j] : PE ? pf[(int64_t)(j * R + t) * ps] : s_flags[j * R + t];
         };
 
         double supp[NR];   // environment.py:241
@@ -616,8 +620,8 @@ static int validate_io(const macjd_scenario* s, const macjd_step_io* io) {
     if ((io->pd && (io->pd_se == 0 && io->pd_sx == 0)) || (io->snr_with && (io->sw_se == 0 && io->sw_sx == 0)))
         return set_err(MACJD_EINVAL, "macjd_env_step: output strides are zero");
     if (io->k_se == 0 && io->k_sx == 0) return set_err(MACJD_EINVAL, "macjd_env_step: track strides are zero");
-    if (io->pe_tables && (!io->pe_flags || io->pe_stride < io->n_envs))
-        return set_err(MACJD_EINVAL, "macjd_env_step: per-env tables need pe_flags and pe_stride >= n_envs");
+    if (io->pe_tables && (!io->pe_flags || io->pe_tile < 0 || (io->pe_tile == 0 && io->pe_stride < io->n_envs)))
+        return set_err(MACJD_EINVAL, "macjd_env_step: per-env tables need pe_flags and pe_stride >= n_envs (or pe_tile > 0)");
     return MACJD_OK;
 }
 

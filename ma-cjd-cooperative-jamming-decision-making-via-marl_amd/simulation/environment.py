@@ -61,6 +61,8 @@ class BatchedElectromagneticEnvironment:
     # The observation is a pure function of static scenario parameters (environment.py:479-510; nothing
     # in step() moves an entity), so runners may fill their obs / state / avail rows once.
     observation_is_static = True
+    PE_TILE = 256            # envs per tile of the per-env tables (= the lane kernel's workgroup at streaming sizes)
+    pe_tiled = True          # A/B hook: False keeps the plain [rows, E] SoA on the device
 
     def __init__(self, config: Any = None, sim_config_path: str = DEFAULT_SIM_CONFIG_PATH,
                  batch_envs: Optional[int] = None, device=None, seed: Optional[int] = None,
@@ -108,8 +110,19 @@ class BatchedElectromagneticEnvironment:
         self._snr_no = torch.from_numpy(sc.tables["radar_snr_no"]).to(dev)
         self._pe_tables = self._pe_flags = self._state_vecs = None
         if scenario_batch is not None:
-            self._pe_tables = torch.from_numpy(scenario_batch.tables).to(dev)       # f64 [rows, E]
-            self._pe_flags = torch.from_numpy(scenario_batch.flags).to(dev)         # u8  [J*R, E]
+            # tiled (AoSoA) device form: [n_tiles, rows, PE_TILE] — a workgroup's 256 consecutive envs read one
+            # contiguous block per step (the plain [rows, E] SoA is 6R+3J+JR streams E*8 bytes apart)
+            self._pe_tile = self.PE_TILE if getattr(self, "pe_tiled", True) else 0
+            tb, fl = scenario_batch.tables, scenario_batch.flags
+            if self._pe_tile:
+                w = self._pe_tile
+                n_tiles = (E + w - 1) // w
+                pad = n_tiles * w - E
+                tile = lambda a: np.ascontiguousarray(
+                    np.pad(a, ((0, 0), (0, pad))).reshape(a.shape[0], n_tiles, w).transpose(1, 0, 2))
+                tb, fl = tile(tb), tile(fl)
+            self._pe_tables = torch.from_numpy(tb).to(dev)       # f64 [rows, E] or [n_tiles, rows, w]
+            self._pe_flags = torch.from_numpy(fl).to(dev)        # u8  [J*R, E] or [n_tiles, J*R, w]
             self._state_vecs = torch.from_numpy(scenario_batch.state_vectors).to(dev)   # f32 [E, S]
             self._snr_no = torch.from_numpy(scenario_batch.snr_no).to(dev)          # f64 [E, R]
         self._io = _native.StepIO()
@@ -214,6 +227,7 @@ class BatchedElectromagneticEnvironment:
         io.r_dpj_sum = rdpj_sum.data_ptr() if rdpj_sum is not None else None
         if self._pe_tables is not None:
             io.pe_tables, io.pe_flags, io.pe_stride = self._pe_tables.data_ptr(), self._pe_flags.data_ptr(), E
+            io.pe_tile = self._pe_tile
         # keep converted tensors alive until the launch has been enqueued (same-stream ordering
         # keeps their storage valid for the kernel: the caching allocator is stream-ordered)
         self._keep = (T, P, u, rew, ter, diag)

@@ -31,6 +31,7 @@ class StepIO(ctypes.Structure):
         ("out64", ctypes.c_void_p), ("pd64", ctypes.c_void_p), ("snr64", ctypes.c_void_p),
         ("prj64", ctypes.c_void_p),
         ("pe_tables", ctypes.c_void_p), ("pe_flags", ctypes.c_void_p), ("pe_stride", ctypes.c_int64),
+        ("pe_tile", ctypes.c_int32), ("reserved_pe", ctypes.c_int32),
         ("r_dpj_sum", ctypes.c_void_p),
     ]
 
