@@ -312,15 +312,20 @@ def test_per_env_batch_equals_single_scenario_envs_and_oracle():
         BatchedElectromagneticEnvironment(scenario_batch=batch, batch_envs=E + 1, device="cuda:0")
 
 
+@pytest.mark.parametrize("tiled", [True, False])
 @pytest.mark.parametrize("J,R", [(5, 7), (2, 2), (6, 8)])
-def test_per_env_tables_other_sizes_vs_oracle(J, R):
+def test_per_env_tables_other_sizes_vs_oracle(J, R, tiled, monkeypatch):
     """Per-env tables on the generic kernel variant (5j/7r: run-time sizes, table reads at their use sites) and on
     other compile-time sizes, against the oracle run per env on that env's own scenario; supplied uniforms."""
     from macjd_amd.scenario import ScenarioBatch, ring_scenario_dict
     from macjd_amd.simulation.environment import BatchedElectromagneticEnvironment
     E = 33
     batch = ScenarioBatch.randomized(ring_scenario_dict(J, R), E, seed=J * 100 + R)
+    # both device layouts of the tables: tiles of 8 envs (33 envs = 4 full tiles + a padded one) and the plain SoA
+    monkeypatch.setattr(BatchedElectromagneticEnvironment, "pe_tiled", tiled)
+    monkeypatch.setattr(BatchedElectromagneticEnvironment, "PE_TILE", 8)
     env = BatchedElectromagneticEnvironment(scenario_batch=batch, device="cuda:0")
+    assert env._pe_tile == (8 if tiled else 0)
     oracles = [OracleEnv(sc, 1) for sc in batch.scenarios]
     env.reset()
     rng = np.random.default_rng(J + R)
