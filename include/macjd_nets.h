@@ -259,6 +259,25 @@ typedef struct macjd_mlp_io {
 /* One launch, no workspace: the weights are read in torch's own [out, in] layout (LDS-DMA into padded LDS rows). */
 int macjd_mlp_forward(const macjd_mlp_io* io, void* hip_stream);
 
+/*
+ * Gate arithmetic of one GRU cell step for N rows (torch.nn.GRUCell after its two GEMMs, reference
+ * core/networks.py:100-113): given gi = W_ih x + b_ih and gh = W_hh h + b_hh ([N,3H], gate order r, z, n),
+ *   r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r gh_n), h' = (h - n) z + n,
+ * written to h_out and, optionally, to a second destination (the batched runner's staging row) in the same launch
+ * (replaces the fused-cell launch + the copy).  H must be a multiple of 4; h_out may alias h.
+ */
+typedef struct macjd_grugates_io {
+    int64_t n_rows;
+    int32_t H, reserved;
+    const float* gi;  int64_t gi_ld;
+    const float* gh;  int64_t gh_ld;
+    const float* h;   int64_t h_ld;
+    float* h_out;     int64_t ho_ld;
+    float* h_out2;    int64_t ho2_ld;   /* optional */
+} macjd_grugates_io;
+
+int macjd_gru_gates(const macjd_grugates_io* io, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

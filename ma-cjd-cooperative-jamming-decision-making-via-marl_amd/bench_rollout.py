@@ -64,15 +64,21 @@ def make_step(cli, sc, env, dev, rank, world, mode):
             learner.enable_graphs(buf, args.batch_size)
     if use_graphs:
         runner.enable_graph()
-    total = cli.warmup + cli.steps
     state = {"graphed_episode": False}
 
     def step_fn(i):
-        t = i % T
+        # Episodes are aligned to the regions the caller times: the warm-up steps are their own run of episodes and
+        # the timed steps start a fresh episode batch at step `warmup`.  A whole episode batch (reset + T batched
+        # steps) is ONE graph launch when it lies completely inside its region; otherwise (the partial episode at
+        # the end of a region) the steps are launched one by one.  Without the alignment a graph launched during
+        # warm-up would do the work of later, timed, steps before the clock starts.
+        if i < cli.warmup:
+            j, region = i, cli.warmup
+        else:
+            j, region = i - cli.warmup, cli.steps
+        t = j % T
         if t == 0:
-            # a whole episode batch (reset + T batched steps) is ONE graph launch when it fits in the
-            # remaining step budget; otherwise (trailing partial episode) the steps are launched one by one
-            state["graphed_episode"] = use_graphs and (i + T <= total)
+            state["graphed_episode"] = use_graphs and (j + T <= region)
             if state["graphed_episode"]:
                 runner.rollout_graphed()
             else:

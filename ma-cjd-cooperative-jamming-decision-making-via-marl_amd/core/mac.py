@@ -42,6 +42,9 @@ class BasicMAC:
         # optional (int32 [E,J,1], float32 [E,J,1]) destinations for the chosen actions of the NEXT select_actions call
         # on a HIP device (the batched runner points them at its staging rows: no copy, the env kernel reads them there)
         self.action_out = None
+        # optional float32 [E,J,H] destination that also receives the post-update hidden state of the NEXT
+        # select_actions call (the batched runner's staging row: no separate copy launch)
+        self.hidden_out = None
 
     def select_actions(self, obs_batch, avail_actions_batch, t_env, test_mode=False):
         device = next(self.agent.parameters()).device
@@ -54,7 +57,8 @@ class BasicMAC:
         batch_size = obs_batch.shape[0]
         obs_reshaped = obs_batch.reshape(-1, self.input_shape)
         with torch.no_grad():
-            h_new, params_all = self.forward(obs_reshaped, self.hidden_states)
+            h_new, params_all = self.forward(obs_reshaped, self.hidden_states, h_out2=self.hidden_out)
+            self.hidden_out = None
             self.hidden_states = h_new.detach()  # mac.py:107
             agent = self.agent
             H, A = agent.rnn_hidden_dim, agent.n_actions
@@ -89,9 +93,14 @@ class BasicMAC:
             self.last_actions_P = chosen_p
             return chosen, chosen_p
 
-    def forward(self, agent_inputs_reshaped, hidden_states):
+    def forward(self, agent_inputs_reshaped, hidden_states, h_out2=None):
         """-> (h' [N, H], continuous params for all actions [N, A])  (mac.py:168-187)."""
-        h_out = self.agent.forward(agent_inputs_reshaped, hidden_states)
+        if h_out2 is not None and agent_inputs_reshaped.is_cuda and not torch.is_grad_enabled():
+            h_out = self.agent.forward(agent_inputs_reshaped, hidden_states, h_out2=h_out2)
+        else:
+            h_out = self.agent.forward(agent_inputs_reshaped, hidden_states)
+            if h_out2 is not None:
+                h_out2.view(h_out.shape).copy_(h_out.detach())
         return h_out, self.agent.actor_forward(agent_inputs_reshaped)
 
     def init_hidden(self, batch_size):

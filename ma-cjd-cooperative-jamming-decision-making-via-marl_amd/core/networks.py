@@ -78,12 +78,13 @@ class RNNAgent(nn.Module):
             return ops.mlp_forward(agent_inputs, layers)
         return ops.mlp_reference(agent_inputs, layers)
 
-    def forward(self, agent_inputs, h_in):
-        """h' = GRUCell(ReLU(fc1 obs), h)  (networks.py:88-114)."""
+    def forward(self, agent_inputs, h_in, h_out2=None):
+        """h' = GRUCell(ReLU(fc1 obs), h)  (networks.py:88-114).  ``h_out2``: optional second destination of h' on
+        the HIP inference path (the batched runner's staging row)."""
         if self._fused_ok(agent_inputs) and agent_inputs.dim() == 2:
-            gi = self.gru_input_transform(agent_inputs)                       # one fused launch
+            gi = self.gru_input_transform(agent_inputs)
             gh = F.linear(h_in.to(gi.device), self.rnn.weight_hh, self.rnn.bias_hh)
-            return torch.ops.aten._thnn_fused_gru_cell(gi, gh, h_in.contiguous())[0]
+            return ops.gru_gates(gi, gh, h_in, out2=h_out2)                   # gates + both stores: one launch
         x = F.relu(self.fc1(agent_inputs))
         if h_in.device != x.device:
             h_in = h_in.to(x.device)

@@ -778,3 +778,57 @@ extern "C" int macjd_layernorm_forward(const macjd_layernorm_io* io, void* hip_s
     if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
     return MACJD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// GRU gates of the rollout step: elementwise, no LDS (it runs beside the actor's LDS-heavy dense chain in the replayed
+// graph), 4 hidden units per thread with 16-byte loads; writes h' to the hidden buffer and the staging row.
+namespace macjd {
+
+__global__ void __launch_bounds__(256) gru_gates_kernel(const macjd_grugates_io io) {
+    const int H = io.H, q = H >> 2;
+    const int64_t total = io.n_rows * q;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / q;
+        const int u = (int)(i - n * q) * 4;
+        const float* gi = io.gi + n * io.gi_ld + u;
+        const float* gh = io.gh + n * io.gh_ld + u;
+        float ir[4], iz[4], in_[4], hr[4], hz[4], hn[4], hp[4], out[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ir[k] = gi[k]; iz[k] = gi[H + k]; in_[k] = gi[2 * H + k];
+            hr[k] = gh[k]; hz[k] = gh[H + k]; hn[k] = gh[2 * H + k];
+            hp[k] = io.h[n * io.h_ld + u + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float r = 1.0f / (1.0f + expf(-(ir[k] + hr[k])));
+            const float z = 1.0f / (1.0f + expf(-(iz[k] + hz[k])));
+            const float nn = tanhf(in_[k] + r * hn[k]);
+            out[k] = (hp[k] - nn) * z + nn;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            io.h_out[n * io.ho_ld + u + k] = out[k];
+            if (io.h_out2) io.h_out2[n * io.ho2_ld + u + k] = out[k];
+        }
+    }
+}
+
+}  // namespace macjd
+
+extern "C" int macjd_gru_gates(const macjd_grugates_io* io, void* hip_stream) {
+    using namespace macjd;
+    if (!io || io->n_rows < 0 || io->H < 4 || (io->H & 3) || !io->gi || !io->gh || !io->h || !io->h_out)
+        return set_nets_err(MACJD_EINVAL, "macjd_gru_gates: bad argument (H must be a positive multiple of 4)");
+    if (io->gi_ld < 3 * io->H || io->gh_ld < 3 * io->H || io->h_ld < io->H || io->ho_ld < io->H ||
+        (io->h_out2 && io->ho2_ld < io->H))
+        return set_nets_err(MACJD_EINVAL, "macjd_gru_gates: row stride smaller than the row");
+    if (io->n_rows == 0) return MACJD_OK;
+    const int64_t total = io->n_rows * (io->H >> 2);
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(gru_gates_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0,
+                       (hipStream_t)hip_stream, *io);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
+    return MACJD_OK;
+}

@@ -219,6 +219,35 @@ def gru_sequence_multi(gis, w_hhs, b_hhs, h0s=None):
     return outs
 
 
+def gru_gates(gi, gh, h, out2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """h' [N, H] of one GRUCell step from gi = W_ih x + b_ih and gh = W_hh h + b_hh (inference).  HIP device: one
+    LDS-free elementwise launch that can also write h' to a second [N, H] destination (``out2``: the runner's staging
+    row); host tensors: the same arithmetic with torch ops."""
+    N, H = h.shape
+    if not h.is_cuda or (H & 3):
+        r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+        z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+        n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+        hn = (h - n) * z + n
+        if out2 is not None:
+            out2.view(N, H).copy_(hn)
+        return hn
+    lib = _native.load()
+    gi, gh, h = _f32c(gi.detach()), _f32c(gh.detach()), _f32c(h.detach())
+    out = torch.empty((N, H), dtype=torch.float32, device=h.device)
+    io = _native.GruGatesIO()
+    io.n_rows, io.H = N, H
+    io.gi, io.gi_ld, io.gh, io.gh_ld = gi.data_ptr(), gi.stride(0), gh.data_ptr(), gh.stride(0)
+    io.h, io.h_ld, io.h_out, io.ho_ld = h.data_ptr(), h.stride(0), out.data_ptr(), out.stride(0)
+    if out2 is not None:
+        o2 = out2.view(N, H)
+        assert o2.dtype == torch.float32 and o2.stride(1) == 1 and o2.device == h.device
+        io.h_out2, io.ho2_ld = o2.data_ptr(), o2.stride(0)
+    with torch.cuda.device(h.device):
+        _native.check(lib.macjd_gru_gates(ctypes.byref(io), _stream(h)), "macjd_gru_gates")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # QMix mixer tail (reference core/networks.py:283-315)
 def mixer_tail_reference(q, w1_raw, b1_raw, wf_raw, v_raw):

@@ -218,10 +218,12 @@ class BatchedEpisodeRunner:
         # eager and graph-replayed rollouts (select_actions pre-increments its call counter)
         mac._select_calls = self._ep * (self.episode_limit + 1) + t
         on_device = self._obs.is_cuda
-        if on_device:   # the fused select kernel writes the chosen actions straight into this step's staging rows
+        if on_device:   # the fused kernels write the chosen actions and the post-update h_t straight into this step's rows
             mac.action_out = (st["actions_discrete"][t], st["actions_continuous"][t])
+            mac.hidden_out = st["hidden_state"][t]
         T64, P_sel = mac.select_actions(self._obs, self._avail, self.t_env, test_mode=test_mode)
-        st["hidden_state"][t].copy_(mac.hidden_states.view(E, J, -1))  # post-update h_t
+        if not on_device:
+            st["hidden_state"][t].copy_(mac.hidden_states.view(E, J, -1))  # post-update h_t
         if on_device:
             T32, P_sel = st["actions_discrete"][t], st["actions_continuous"][t]
         else:

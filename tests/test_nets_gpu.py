@@ -414,6 +414,29 @@ def test_graphed_rollout_equals_eager_rollout():
             assert torch.equal(a, b), k
 
 
+@pytest.mark.parametrize("N,H", [(1, 64), (63, 64), (12288, 64), (100, 128)])
+def test_gru_gates_kernel_vs_torch_cell(N, H):
+    """Gates + both stores in one launch == torch.nn.GRUCell on the host; strided gi / second destination."""
+    from macjd_amd import ops
+    g = torch.Generator().manual_seed(N + H)
+    cell = torch.nn.GRUCell(H, H)
+    with torch.no_grad():
+        for p_ in cell.parameters():
+            p_.copy_(0.3 * torch.randn(p_.shape, generator=g))
+    x, h = torch.randn(N, H, generator=g), torch.randn(N, H, generator=g)
+    with torch.no_grad():
+        ref = cell(x, h)
+        gi = torch.nn.functional.linear(x, cell.weight_ih, cell.bias_ih)
+        gh = torch.nn.functional.linear(h, cell.weight_hh, cell.bias_hh)
+    wide = torch.zeros(N, 3 * H + 8, device=DEV)
+    wide[:, 4:4 + 3 * H] = gi.to(DEV)
+    stage = torch.full((2, N, H), -7.0, device=DEV)
+    out = ops.gru_gates(wide[:, 4:4 + 3 * H], gh.to(DEV), h.to(DEV), out2=stage[1])
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=TOL, rtol=0)
+    assert torch.equal(stage[1], out) and float((stage[0] != -7.0).sum()) == 0
+    np.testing.assert_allclose(ops.gru_gates(gi, gh, h).numpy(), ref.numpy(), atol=TOL, rtol=0)   # host form
+
+
 def test_gru_sequence_kernel_strided_initial_state():
     """h0 handed over as step 0 of a stored [B, T+1, J, H] tensor (batch stride (T+1) J H): no copy, same result."""
     from macjd_amd import ops
