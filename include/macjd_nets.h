@@ -252,7 +252,7 @@ typedef struct macjd_mlp_io {
     int32_t act[3];          /* MACJD_ACT_* per layer */
     const float* W[3];       /* [dims[l+1], dims[l]] contiguous */
     const float* b[3];       /* [dims[l+1]] */
-    const float* x;  int64_t x_ld;   /* [n_rows, dims[0]], row stride in elements */
+    const float* x;  int64_t x_ld;   /* [n_rows, dims[0]], row stride in elements (0 = one row broadcast to all) */
     float* y;        int64_t y_ld;   /* [n_rows, dims[n_layers]] */
 } macjd_mlp_io;
 

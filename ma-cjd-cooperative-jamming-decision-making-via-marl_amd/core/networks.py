@@ -60,21 +60,24 @@ class RNNAgent(nn.Module):
         """zeros [1, H] on the parameters' device (networks.py:81-86)."""
         return self.fc1.weight.new_zeros(1, self.rnn_hidden_dim)
 
-    # Which chains go through the fused MFMA kernel (ops.mlp_forward) on a HIP device under no_grad.  Measured
-    # on MI355X, N = 12 288 rows (scripts/bench_kernels.py, graph replay): actor 46-128-128-9: 24 us fused vs 39 us
-    # as 3 library GEMMs + 3 activation launches; fc1 + GRU input transform 46-64-192: 20 us vs 18 us -> library.
+    # Which chains go through the fused MFMA kernel (ops.mlp_forward) on a HIP device under no_grad.  Measured on MI355X
+    # (bench.py, episode-aligned accounting): actor 46-128-128-9 at 12 288 rows: 15.5 us fused vs 39 us as 3 library
+    # GEMMs + 3 activation launches; fc1 + GRU input transform 46-64-192: one 14 us launch vs 6.6 + 4.8 + 11.1 us in the
+    # rollout step's serial chain (rollout 0.0793 -> 0.0744 ms / step), no gain for the learner's 9 696-row
+    # time-parallel transform (train 0.502 vs 0.505 ms), which therefore stays on library GEMMs.
     fused_actor = os.environ.get("MACJD_FUSED_ACTOR", "1") != "0"
-    fused_gi = os.environ.get("MACJD_FUSED_GI", "0") != "0"
+    fused_gi = os.environ.get("MACJD_FUSED_GI", "0") != "0"                   # learner's time-parallel transform
+    fused_gi_step = os.environ.get("MACJD_FUSED_GI_STEP", "1") != "0"         # the rollout step (RNNAgent.forward)
 
     def _fused_ok(self, t):
         """Inference on a HIP device: the fused MFMA chain (ops.mlp_forward) replaces Linear + activation
         launches.  With autograd on, the stock modules run (the fused kernels have no backward)."""
         return t.is_cuda and not torch.is_grad_enabled()
 
-    def gru_input_transform(self, agent_inputs):
+    def gru_input_transform(self, agent_inputs, fused=None):
         """W_ih ReLU(fc1 obs) + b_ih, [N, 3H]: the time-parallel half of the GRU step (networks.py:100)."""
         layers = [(self.fc1.weight, self.fc1.bias, ops.ACT_RELU), (self.rnn.weight_ih, self.rnn.bias_ih, ops.ACT_NONE)]
-        if self.fused_gi and self._fused_ok(agent_inputs):
+        if (self.fused_gi if fused is None else fused) and self._fused_ok(agent_inputs):
             return ops.mlp_forward(agent_inputs, layers)
         return ops.mlp_reference(agent_inputs, layers)
 
@@ -82,7 +85,7 @@ class RNNAgent(nn.Module):
         """h' = GRUCell(ReLU(fc1 obs), h)  (networks.py:88-114).  ``h_out2``: optional second destination of h' on
         the HIP inference path (the batched runner's staging row)."""
         if self._fused_ok(agent_inputs) and agent_inputs.dim() == 2:
-            gi = self.gru_input_transform(agent_inputs)
+            gi = self.gru_input_transform(agent_inputs, fused=self.fused_gi_step)
             gh = F.linear(h_in.to(gi.device), self.rnn.weight_hh, self.rnn.bias_hh)
             return ops.gru_gates(gi, gh, h_in, out2=h_out2)                   # gates + both stores: one launch
         x = F.relu(self.fc1(agent_inputs))

@@ -345,7 +345,8 @@ extern "C" int macjd_mlp_forward(const macjd_mlp_io* io, void* hip_stream) {
         biggest = img > biggest ? img : biggest;
         widest = K > widest ? K : widest;   // the strip holds the inputs of every layer
     }
-    if (io->x_ld < io->dims[0] || io->y_ld < io->dims[L])
+    // x_ld == 0 is a broadcast input (every row the same vector, e.g. the static observation): fine to read
+    if ((io->x_ld != 0 && io->x_ld < io->dims[0]) || io->y_ld < io->dims[L])
         return set_err(MACJD_EINVAL, "%s", "macjd_mlp_forward: row stride smaller than the row");
     if (io->n_rows == 0) return MACJD_OK;
     g.vec16[3] = (io->dims[0] % 4 == 0) && (io->x_ld % 4 == 0) && (((uintptr_t)io->x) % 16 == 0);
