@@ -784,6 +784,7 @@ extern "C" int macjd_layernorm_forward(const macjd_layernorm_io* io, void* hip_s
 // graph), 4 hidden units per thread with 16-byte loads; writes h' to the hidden buffer and the staging row.
 namespace macjd {
 
+template <bool VEC>
 __global__ void __launch_bounds__(256) gru_gates_kernel(const macjd_grugates_io io) {
     const int H = io.H, q = H >> 2;
     const int64_t total = io.n_rows * q;
@@ -792,24 +793,41 @@ __global__ void __launch_bounds__(256) gru_gates_kernel(const macjd_grugates_io 
         const int u = (int)(i - n * q) * 4;
         const float* gi = io.gi + n * io.gi_ld + u;
         const float* gh = io.gh + n * io.gh_ld + u;
+        const float* hpp = io.h + n * io.h_ld + u;
         float ir[4], iz[4], in_[4], hr[4], hz[4], hn[4], hp[4], out[4];
+        auto ld4 = [](const float* p, float* d) {
+            if (VEC) {
+                const float4 v = *reinterpret_cast<const float4*>(p);
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            ir[k] = gi[k]; iz[k] = gi[H + k]; in_[k] = gi[2 * H + k];
-            hr[k] = gh[k]; hz[k] = gh[H + k]; hn[k] = gh[2 * H + k];
-            hp[k] = io.h[n * io.h_ld + u + k];
-        }
+                for (int k = 0; k < 4; ++k) d[k] = p[k];
+            }
+        };
+        ld4(gi, ir); ld4(gi + H, iz); ld4(gi + 2 * H, in_);
+        ld4(gh, hr); ld4(gh + H, hz); ld4(gh + 2 * H, hn);
+        ld4(hpp, hp);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float r = 1.0f / (1.0f + expf(-(ir[k] + hr[k])));
             const float z = 1.0f / (1.0f + expf(-(iz[k] + hz[k])));
-            const float nn = tanhf(in_[k] + r * hn[k]);
+            // tanh(x) = 1 - 2 / (exp(2x) + 1): saturates cleanly (exp -> inf gives 1, exp -> 0 gives -1), abs. error ~1e-7
+            const float nn = 1.0f - 2.0f / (expf(2.0f * (in_[k] + r * hn[k])) + 1.0f);
             out[k] = (hp[k] - nn) * z + nn;
         }
+        float* o1 = io.h_out + n * io.ho_ld + u;
+        if (VEC) *reinterpret_cast<float4*>(o1) = float4{out[0], out[1], out[2], out[3]};
+        else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            io.h_out[n * io.ho_ld + u + k] = out[k];
-            if (io.h_out2) io.h_out2[n * io.ho2_ld + u + k] = out[k];
+            for (int k = 0; k < 4; ++k) o1[k] = out[k];
+        }
+        if (io.h_out2) {
+            float* o2 = io.h_out2 + n * io.ho2_ld + u;
+            if (VEC) *reinterpret_cast<float4*>(o2) = float4{out[0], out[1], out[2], out[3]};
+            else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o2[k] = out[k];
+            }
         }
     }
 }
@@ -826,8 +844,12 @@ extern "C" int macjd_gru_gates(const macjd_grugates_io* io, void* hip_stream) {
     if (io->n_rows == 0) return MACJD_OK;
     const int64_t total = io->n_rows * (io->H >> 2);
     const int64_t blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(gru_gates_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0,
-                       (hipStream_t)hip_stream, *io);
+    auto al = [](const void* p, int64_t ld) { return (((uintptr_t)p) % 16 == 0) && (ld % 4 == 0); };
+    const bool vec = al(io->gi, io->gi_ld) && al(io->gh, io->gh_ld) && al(io->h, io->h_ld) && al(io->h_out, io->ho_ld) &&
+                     (!io->h_out2 || al(io->h_out2, io->ho2_ld));
+    const dim3 g((unsigned)(blocks < 8192 ? blocks : 8192)), b(256);
+    if (vec) hipLaunchKernelGGL(gru_gates_kernel<true>, g, b, 0, (hipStream_t)hip_stream, *io);
+    else hipLaunchKernelGGL(gru_gates_kernel<false>, g, b, 0, (hipStream_t)hip_stream, *io);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
     return MACJD_OK;
