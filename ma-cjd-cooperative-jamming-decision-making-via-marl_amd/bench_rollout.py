@@ -62,25 +62,32 @@ def make_step(cli, sc, env, dev, rank, world, mode):
         runner.run(test_mode=False, sync_stats=False)  # untimed pre-fill of the replay buffer
         if use_graphs:
             learner.enable_graphs(buf, args.batch_size)
+    tails = set()
     if use_graphs:
         runner.enable_graph()
+        # the partial episode at the end of the warm-up / timed region gets its own (shorter) graph, so every step of
+        # the run is replayed from a graph whatever --steps / --warmup are
+        tails = {r % T for r in (cli.warmup, cli.steps) if r % T}
+        for n in sorted(tails):
+            runner.enable_graph(n_steps=n)
     state = {"graphed_episode": False}
 
     def step_fn(i):
         # Episodes are aligned to the regions the caller times: the warm-up steps are their own run of episodes and
         # the timed steps start a fresh episode batch at step `warmup`.  A whole episode batch (reset + T batched
-        # steps) is ONE graph launch when it lies completely inside its region; otherwise (the partial episode at
-        # the end of a region) the steps are launched one by one.  Without the alignment a graph launched during
-        # warm-up would do the work of later, timed, steps before the clock starts.
+        # steps) is ONE graph launch; the partial episode at the end of a region replays its own shorter graph.
+        # Without the alignment a graph launched during warm-up would do the work of later, timed, steps before
+        # the clock starts.
         if i < cli.warmup:
             j, region = i, cli.warmup
         else:
             j, region = i - cli.warmup, cli.steps
         t = j % T
         if t == 0:
-            state["graphed_episode"] = use_graphs and (j + T <= region)
+            left = region - j
+            state["graphed_episode"] = use_graphs and (left >= T or left in tails)
             if state["graphed_episode"]:
-                runner.rollout_graphed()
+                runner.rollout_graphed(None if left >= T else left)
             else:
                 runner.begin_episodes()
         if not state["graphed_episode"]:

@@ -245,30 +245,40 @@ class BatchedEpisodeRunner:
             self.buffer.store_episodes_batched(self.stage, self.batch_envs)
 
     # ---- HIP-graph replay of a whole episode batch ----
-    def enable_graph(self):
-        """Capture reset + all ``episode_limit`` batched steps (~25 launches each) as ONE HIP graph.
+    def enable_graph(self, n_steps=None):
+        """Capture reset + ``n_steps`` batched steps (default: a whole episode, ``episode_limit``) as ONE HIP graph.
         Kernel arguments are frozen at capture, so the two per-step scalars that change between episodes —
         the exploration probability and the Philox call counter of the select kernel — are read from device
-        memory (``_eps_sched[t]``, ``_ctr_base``) that ``rollout_graphed`` refreshes before each replay."""
+        memory (``_eps_sched[t]``, ``_ctr_base``) that ``rollout_graphed`` refreshes before each replay.
+        Shorter graphs (the first ``n_steps`` steps of an episode batch) can be captured alongside the full one;
+        ``rollout_graphed(n_steps)`` picks the matching graph."""
         T = self.episode_limit
+        n = T if n_steps is None else int(n_steps)
+        if not 1 <= n <= T:
+            raise ValueError(f"enable_graph: n_steps must be in 1..{T}, got {n_steps}")
         dev = self.device
-        self._eps_sched = torch.zeros(T, dtype=torch.float32, device=dev)
-        self._ctr_base = torch.zeros(1, dtype=torch.int64, device=dev)
+        if getattr(self, "_graphs", None) is None:
+            self._graphs = {}
+            self._eps_sched = torch.zeros(T, dtype=torch.float32, device=dev)
+            self._ctr_base = torch.zeros(1, dtype=torch.int64, device=dev)
         t_env0, ep0 = self.t_env, self._ep
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):  # warm-up outside capture
-            self._rollout_body(device_schedule=True)
+            self._rollout_body(device_schedule=True, n_steps=n)
         torch.cuda.current_stream(dev).wait_stream(s)
-        self._graph = torch.cuda.CUDAGraph()
+        graph = torch.cuda.CUDAGraph()
         # thread_local: other threads (RCCL's watchdog polls events) may touch the runtime during capture
-        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
-            self._rollout_body(device_schedule=True)
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            self._rollout_body(device_schedule=True, n_steps=n)
+        self._graphs[n] = graph
+        if n == T:
+            self._graph = graph
         self.t_env, self._ep = t_env0, ep0
         self.mac.device_schedule = None
 
-    def _rollout_body(self, device_schedule=False):
-        T = self.episode_limit
+    def _rollout_body(self, device_schedule=False, n_steps=None):
+        T = self.episode_limit if n_steps is None else n_steps
         self.begin_episodes()
         for t in range(T):
             if device_schedule:
@@ -276,18 +286,19 @@ class BatchedEpisodeRunner:
             self.step(t, test_mode=False)
         self.mac.device_schedule = None
 
-    def rollout_graphed(self):
-        """Enqueue one whole episode batch by replaying the captured graph (training mode)."""
+    def rollout_graphed(self, n_steps=None):
+        """Enqueue one episode batch (or its first ``n_steps`` steps) by replaying the captured graph (training mode)."""
         T = self.episode_limit
+        n = T if n_steps is None else int(n_steps)
         sel = self.mac.action_selector
-        eps = np.empty(T, dtype=np.float32)
-        for t in range(T):
+        eps = np.zeros(T, dtype=np.float32)
+        for t in range(n):
             eps[t] = sel.anneal(self.t_env + t, test_mode=False)
         self._eps_sched.copy_(torch.from_numpy(eps))
         self._ep += 1
         self._ctr_base.fill_(self._ep * (T + 1))
-        self._graph.replay()
-        self.t_env += T
+        self._graphs[n].replay()
+        self.t_env += n
 
     def run(self, test_mode=False, store=True, sync_stats=True):
         """One batch of E episodes.  Returns the reference's ``run_info`` keys as means over the E
