@@ -157,8 +157,11 @@ class QMixLearner:
         import torch.distributed as dist
         if self._world_size() <= 1:
             return
-        dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
-        self._flat_grad.div_(dist.get_world_size())
+        if dist.get_backend() == "nccl":   # RCCL averages in the collective: no separate divide launch
+            dist.all_reduce(self._flat_grad, op=dist.ReduceOp.AVG)
+        else:                              # gloo (CPU tests) has no AVG
+            dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
+            self._flat_grad.div_(dist.get_world_size())
 
     # ------------------------------------------------------------------ the training step
     def _forward_backward(self, batch, T, validate_actions=True):
