@@ -260,6 +260,22 @@ typedef struct macjd_mlp_io {
 int macjd_mlp_forward(const macjd_mlp_io* io, void* hip_stream);
 
 /*
+ * y[n] = x[n, :] . w + b for a Linear layer with ONE output feature (the Q-head's second layer and the mixer's V
+ * head, reference core/networks.py:78,247): one launch instead of a bias-broadcast copy + a 16 x 256-tile GEMM.
+ * K <= 1024, K % 4 == 0.
+ */
+typedef struct macjd_rowdot_io {
+    int64_t n_rows;
+    int32_t K, reserved;
+    const float* x;  int64_t x_ld;   /* [n_rows, K] row stride in elements */
+    const float* w;                  /* [K] */
+    const float* b;                  /* [1] or NULL */
+    float* y;                        /* [n_rows] contiguous */
+} macjd_rowdot_io;
+
+int macjd_rowdot(const macjd_rowdot_io* io, void* hip_stream);
+
+/*
  * Gate arithmetic of one GRU cell step for N rows (torch.nn.GRUCell after its two GEMMs, reference
  * core/networks.py:100-113): given gi = W_ih x + b_ih and gh = W_hh h + b_hh ([N,3H], gate order r, z, n),
  *   r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r gh_n), h' = (h - n) z + n,

@@ -24,7 +24,7 @@ EXPORTS = [
     "macjd_env_reset", "macjd_env_step", "macjd_env_step_timed",
     "macjd_qhead_select", "macjd_gru_sequence", "macjd_mixer_tail_forward", "macjd_mixer_tail_backward",
     "macjd_mlp_forward", "macjd_td_loss", "macjd_clip_adam_step", "macjd_gather_rows",
-    "macjd_linear_wgrad", "macjd_linear_wgrad_workspace_floats", "macjd_qhead_input", "macjd_layernorm_forward", "macjd_gru_gates",
+    "macjd_linear_wgrad", "macjd_linear_wgrad_workspace_floats", "macjd_qhead_input", "macjd_layernorm_forward", "macjd_gru_gates", "macjd_rowdot",
 ]
 
 
@@ -114,6 +114,15 @@ class GruGatesIO(ctypes.Structure):
         ("gi", ctypes.c_void_p), ("gi_ld", ctypes.c_int64), ("gh", ctypes.c_void_p), ("gh_ld", ctypes.c_int64),
         ("h", ctypes.c_void_p), ("h_ld", ctypes.c_int64),
         ("h_out", ctypes.c_void_p), ("ho_ld", ctypes.c_int64), ("h_out2", ctypes.c_void_p), ("ho2_ld", ctypes.c_int64),
+    ]
+
+
+class RowdotIO(ctypes.Structure):
+    """ctypes mirror of ``macjd_rowdot_io`` (include/macjd_nets.h)."""
+    _fields_ = [
+        ("n_rows", ctypes.c_int64), ("K", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("x", ctypes.c_void_p), ("x_ld", ctypes.c_int64), ("w", ctypes.c_void_p), ("b", ctypes.c_void_p),
+        ("y", ctypes.c_void_p),
     ]
 
 
@@ -224,6 +233,8 @@ def load() -> ctypes.CDLL:
     lib.macjd_layernorm_forward.argtypes = [ctypes.POINTER(LayerNormIO), ctypes.c_void_p]
     lib.macjd_gru_gates.restype = ctypes.c_int
     lib.macjd_gru_gates.argtypes = [ctypes.POINTER(GruGatesIO), ctypes.c_void_p]
+    lib.macjd_rowdot.restype = ctypes.c_int
+    lib.macjd_rowdot.argtypes = [ctypes.POINTER(RowdotIO), ctypes.c_void_p]
     lib.macjd_mlp_forward.restype = ctypes.c_int
     lib.macjd_mlp_forward.argtypes = [ctypes.POINTER(MlpIO), ctypes.c_void_p]
     lib.macjd_td_loss.restype = ctypes.c_int

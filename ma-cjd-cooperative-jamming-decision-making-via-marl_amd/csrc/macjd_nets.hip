@@ -854,3 +854,54 @@ extern "C" int macjd_gru_gates(const macjd_grugates_io* io, void* hip_stream) {
     if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
     return MACJD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Row dot product for Linear layers with one output feature: 16 lanes per row (float4 each, K <= 1024 in up to 16
+// passes), xor-shuffle tree inside the 16-lane group (fixed order: deterministic).
+namespace macjd {
+
+__global__ void __launch_bounds__(256) rowdot_kernel(const macjd_rowdot_io io) {
+    const int sub = threadIdx.x & 15;
+    const int64_t rows_per_block = blockDim.x >> 4;
+    const bool vec = ((io.x_ld & 3) == 0) && ((((uintptr_t)io.x) & 15) == 0) && ((((uintptr_t)io.w) & 15) == 0);
+    const float bias = io.b ? io.b[0] : 0.0f;
+    for (int64_t n = (int64_t)blockIdx.x * rows_per_block + (threadIdx.x >> 4); n < io.n_rows;
+         n += (int64_t)gridDim.x * rows_per_block) {
+        const float* x = io.x + n * io.x_ld;
+        float s = 0.0f;
+        for (int k = sub * 4; k < io.K; k += 64) {
+            float xv[4], wv[4];
+            if (vec) {
+                const float4 a = *reinterpret_cast<const float4*>(x + k), c = *reinterpret_cast<const float4*>(io.w + k);
+                xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w;
+                wv[0] = c.x; wv[1] = c.y; wv[2] = c.z; wv[3] = c.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { xv[i] = x[k + i]; wv[i] = io.w[k + i]; }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s = fmaf(xv[i], wv[i], s);
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 8, 64);
+        if (sub == 0) io.y[n] = s + bias;
+    }
+}
+
+}  // namespace macjd
+
+extern "C" int macjd_rowdot(const macjd_rowdot_io* io, void* hip_stream) {
+    using namespace macjd;
+    if (!io || io->n_rows < 0 || io->K < 4 || io->K > 1024 || (io->K & 3) || !io->x || !io->w || !io->y)
+        return set_nets_err(MACJD_EINVAL, "macjd_rowdot: bad argument (K a multiple of 4 in 4..1024)");
+    if (io->x_ld < io->K) return set_nets_err(MACJD_EINVAL, "macjd_rowdot: row stride smaller than the row");
+    if (io->n_rows == 0) return MACJD_OK;
+    const int64_t blocks = (io->n_rows + 15) / 16;
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0,
+                       (hipStream_t)hip_stream, *io);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
+    return MACJD_OK;
+}

@@ -605,9 +605,55 @@ def layer_norm(x, weight, bias, eps: float = 1e-5):
     return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
 
 
+def _rowdot_launch(x, w, b):
+    lib = _native.load()
+    x = _f32c(x.detach())
+    w = w.detach().reshape(-1).float().contiguous()
+    y = torch.empty((x.shape[0], 1), dtype=torch.float32, device=x.device)
+    io = _native.RowdotIO()
+    io.n_rows, io.K = x.shape[0], x.shape[1]
+    io.x, io.x_ld, io.w, io.y = x.data_ptr(), x.stride(0), w.data_ptr(), y.data_ptr()
+    keep = b.detach().reshape(-1).float().contiguous() if b is not None else None
+    io.b = keep.data_ptr() if keep is not None else None
+    with torch.cuda.device(x.device):
+        _native.check(lib.macjd_rowdot(ctypes.byref(io), _stream(x)), "macjd_rowdot")
+    return y
+
+
+class _RowDot(torch.autograd.Function):
+    """y = x w^T + b for a weight with ONE output row ([1, K]): forward is one row-dot launch (the library path is
+    a bias-broadcast copy + a 16 x 256-tile GEMM); backward: gx = gy w (broadcast product), gW / gb through the split-K
+    weight-gradient kernel like every other Linear."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return _rowdot_launch(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gx = gy * weight.reshape(1, -1) if ctx.needs_input_grad[0] else None
+        gW = gb = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gW, gb = linear_wgrad(gy.reshape(-1, 1), x.reshape(-1, x.shape[-1]), want_bias=ctx.has_bias)
+        return gx, gW, (gb if ctx.has_bias else None)
+
+
+def _rowdot_ok(x, weight):
+    return (x.is_cuda and x.dim() == 2 and weight.shape[0] == 1 and x.dtype == torch.float32 and x.stride(-1) == 1
+            and weight.shape[1] % 4 == 0 and 4 <= weight.shape[1] <= 1024 and x.shape[0] >= 1024
+            and not torch.is_autocast_enabled())
+
+
 def linear(x, weight, bias=None):
     """torch.nn.functional.linear with the split-K weight gradient when it pays: HIP device, autograd on, float32
     (not under the optional bf16 autocast of the mixer), and a reduction of >= 1024 rows into a small weight."""
+    if _rowdot_ok(x, weight):   # one output feature: row-dot kernel (with or without autograd)
+        if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
+            return _RowDot.apply(x, weight, bias)
+        return _rowdot_launch(x, weight, bias)
     if (x.is_cuda and torch.is_grad_enabled() and not torch.is_autocast_enabled() and (weight.requires_grad or (bias is not None and bias.requires_grad))
             and x.dtype == torch.float32 and x.numel() // x.shape[-1] >= 1024 and weight.shape[0] * weight.shape[1] <= 384 * 256
             and x.stride(-1) == 1):

@@ -747,3 +747,27 @@ def test_split_k_weight_gradient_kernel(K, M, N):
     torch.nn.functional.linear(x2, W2, b2).backward(gy)
     for a, r in ((x.grad, x2.grad), (W.grad, W2.grad), (b.grad, b2.grad)):
         np.testing.assert_allclose(a.cpu().numpy(), r.cpu().numpy(), atol=1e-4 * float(r.abs().max()), rtol=1e-4)
+
+
+@pytest.mark.parametrize("N,K", [(3232, 64), (9696, 64), (1024, 128), (5000, 4)])
+def test_rowdot_kernel_single_output_linear(N, K):
+    """Linear layers with one output feature on the row-dot kernel: forward and all gradients == F.linear, with a
+    strided input block (the mixer's V head reads a column block of the merged ReLU output)."""
+    from macjd_amd import ops
+    g = torch.Generator().manual_seed(N + K)
+    wide = torch.randn(N, K + 12, generator=g).to(DEV)
+    x = wide[:, 4:4 + K].detach().requires_grad_(True)
+    W = (torch.randn(1, K, generator=g) / np.sqrt(K)).to(DEV).requires_grad_(True)
+    b = torch.randn(1, generator=g).to(DEV).requires_grad_(True)
+    gy = torch.randn(N, 1, generator=g).to(DEV)
+    y = ops.linear(x, W, b)
+    assert y.shape == (N, 1)
+    y.backward(gy)
+    x2, W2, b2 = (t.detach().clone().requires_grad_(True) for t in (x, W, b))
+    y2 = torch.nn.functional.linear(x2, W2, b2)
+    y2.backward(gy)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y2.detach().cpu().numpy(), atol=2e-6 * np.sqrt(K), rtol=1e-5)
+    for a, r in ((x.grad, x2.grad), (W.grad, W2.grad), (b.grad, b2.grad)):
+        np.testing.assert_allclose(a.cpu().numpy(), r.cpu().numpy(), atol=1e-4 * max(1.0, float(r.abs().max())), rtol=1e-4)
+    with torch.no_grad():
+        assert torch.equal(ops.linear(x, W, b), y.detach())
