@@ -286,11 +286,17 @@ class QMixLearner:
 
     def _finish_update(self, st, T, eval_q_tot, target_q_tot):
         # loss over eval steps 0..T-2 against targets built from target steps 1..T-1 (qmix.py:155,190-194)
-        loss, eval_mean, target_mean = ops.td_loss_full(eval_q_tot, target_q_tot, st["reward"], st["terminated"],
-                                                        st["filled"], self.args.gamma, T - 1, 1)
         for p in self.params:
             p.grad = None
-        loss.backward()
+        if eval_q_tot.is_cuda:
+            # the loss kernel also produces dL/dQ_tot: it seeds the backward pass directly (no ones-fill / multiply)
+            loss, eval_mean, target_mean, gy = ops.td_loss_and_grad(
+                eval_q_tot, target_q_tot, st["reward"], st["terminated"], st["filled"], self.args.gamma, T - 1, 1)
+            eval_q_tot.backward(gy)
+        else:
+            loss, eval_mean, target_mean = ops.td_loss_full(eval_q_tot, target_q_tot, st["reward"], st["terminated"],
+                                                            st["filled"], self.args.gamma, T - 1, 1)
+            loss.backward()
         if self._world_size() > 1 or self._flat_param is not None:
             self._flatten_grads()
         return loss.detach(), eval_mean.detach(), target_mean.detach()

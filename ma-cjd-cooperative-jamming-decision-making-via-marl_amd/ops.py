@@ -425,6 +425,7 @@ class _TdLossHip(torch.autograd.Function):
             _native.check(lib.macjd_td_loss(ctypes.byref(io), _stream(yc)), "macjd_td_loss")
         ctx.save_for_backward(gy)
         ctx.mark_non_differentiable(stats)
+        stats.saved_gy = gy      # for td_loss_and_grad (plain attribute; autograd does not look at it)
         return stats[0], stats
 
     @staticmethod
@@ -438,6 +439,15 @@ def td_loss_full(y_full, tq_full, reward, terminated, filled, gamma, Tm1, tq_off
     tq_off..tq_off+Tm1-1, without slicing either tensor (HIP device only)."""
     loss, stats = _TdLossHip.apply(y_full, tq_full, reward, terminated, filled, gamma, Tm1, tq_off)
     return loss, stats[1], stats[2]
+
+
+def td_loss_and_grad(y_full, tq_full, reward, terminated, filled, gamma, Tm1, tq_off):
+    """(loss, mean(y), mean(target), dL/dy [B, Ty, 1]) in one launch, nothing recorded for autograd: the caller seeds
+    the backward pass with the gradient itself (``y_full.backward(gy)``) — ``loss.backward()`` would first fill a
+    ones tensor for the scalar and multiply the saved gradient by it (three launch-bound kernels)."""
+    with torch.no_grad():
+        _, stats = _TdLossHip.apply(y_full, tq_full, reward, terminated, filled, gamma, Tm1, tq_off)
+    return stats[0], stats[1], stats[2], stats.saved_gy
 
 
 def td_loss(y, tq, reward, terminated, filled, gamma):
