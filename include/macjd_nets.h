@@ -260,6 +260,25 @@ typedef struct macjd_mlp_io {
 int macjd_mlp_forward(const macjd_mlp_io* io, void* hip_stream);
 
 /*
+ * Backward of "ReLU on the first Cr columns of a [M, Cr + Cp] matrix, pass the last Cp columns through, hand the
+ * result out as column blocks" (the merged first layer of the mixer's hyper-networks, reference
+ * core/networks.py:283-299): gout[m, c] = g_k[m, c - start_k] * (act[m, c] > 0) for the ReLU blocks and
+ * g_pass[m, c - Cr] for the pass-through block, written in ONE launch (autograd would run cat + threshold_backward
+ * + cat).  Up to 4 ReLU blocks; a NULL block gradient counts as zero.
+ */
+typedef struct macjd_splitrelu_bwd_io {
+    int64_t M;
+    int32_t n_blocks, Cp;             /* ReLU blocks (1..4); pass-through width (may be 0) */
+    int32_t width[4];                 /* widths of the ReLU blocks, sum = Cr */
+    const float* g[4];  int64_t g_ld[4];     /* block gradients [M, width[k]] */
+    const float* g_pass; int64_t gp_ld;      /* [M, Cp] */
+    const float* act;   int64_t act_ld;      /* [M, Cr] ReLU output saved by the forward */
+    float* gout;        int64_t gout_ld;     /* [M, Cr + Cp] */
+} macjd_splitrelu_bwd_io;
+
+int macjd_splitrelu_backward(const macjd_splitrelu_bwd_io* io, void* hip_stream);
+
+/*
  * y[n] = x[n, :] . w + b for a Linear layer with ONE output feature (the Q-head's second layer and the mixer's V
  * head, reference core/networks.py:78,247): one launch instead of a bias-broadcast copy + a 16 x 256-tile GEMM.
  * K <= 1024, K % 4 == 0.

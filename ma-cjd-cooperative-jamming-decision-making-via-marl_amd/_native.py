@@ -24,7 +24,7 @@ EXPORTS = [
     "macjd_env_reset", "macjd_env_step", "macjd_env_step_timed",
     "macjd_qhead_select", "macjd_gru_sequence", "macjd_mixer_tail_forward", "macjd_mixer_tail_backward",
     "macjd_mlp_forward", "macjd_td_loss", "macjd_clip_adam_step", "macjd_gather_rows",
-    "macjd_linear_wgrad", "macjd_linear_wgrad_workspace_floats", "macjd_qhead_input", "macjd_layernorm_forward", "macjd_gru_gates", "macjd_rowdot",
+    "macjd_linear_wgrad", "macjd_linear_wgrad_workspace_floats", "macjd_qhead_input", "macjd_layernorm_forward", "macjd_gru_gates", "macjd_rowdot", "macjd_splitrelu_backward",
 ]
 
 
@@ -123,6 +123,17 @@ class RowdotIO(ctypes.Structure):
         ("n_rows", ctypes.c_int64), ("K", ctypes.c_int32), ("reserved", ctypes.c_int32),
         ("x", ctypes.c_void_p), ("x_ld", ctypes.c_int64), ("w", ctypes.c_void_p), ("b", ctypes.c_void_p),
         ("y", ctypes.c_void_p),
+    ]
+
+
+class SplitReluBwdIO(ctypes.Structure):
+    """ctypes mirror of ``macjd_splitrelu_bwd_io`` (include/macjd_nets.h)."""
+    _fields_ = [
+        ("M", ctypes.c_int64), ("n_blocks", ctypes.c_int32), ("Cp", ctypes.c_int32), ("width", ctypes.c_int32 * 4),
+        ("g0", ctypes.c_void_p), ("g1", ctypes.c_void_p), ("g2", ctypes.c_void_p), ("g3", ctypes.c_void_p),
+        ("g_ld", ctypes.c_int64 * 4),
+        ("g_pass", ctypes.c_void_p), ("gp_ld", ctypes.c_int64),
+        ("act", ctypes.c_void_p), ("act_ld", ctypes.c_int64), ("gout", ctypes.c_void_p), ("gout_ld", ctypes.c_int64),
     ]
 
 
@@ -233,6 +244,8 @@ def load() -> ctypes.CDLL:
     lib.macjd_layernorm_forward.argtypes = [ctypes.POINTER(LayerNormIO), ctypes.c_void_p]
     lib.macjd_gru_gates.restype = ctypes.c_int
     lib.macjd_gru_gates.argtypes = [ctypes.POINTER(GruGatesIO), ctypes.c_void_p]
+    lib.macjd_splitrelu_backward.restype = ctypes.c_int
+    lib.macjd_splitrelu_backward.argtypes = [ctypes.POINTER(SplitReluBwdIO), ctypes.c_void_p]
     lib.macjd_rowdot.restype = ctypes.c_int
     lib.macjd_rowdot.argtypes = [ctypes.POINTER(RowdotIO), ctypes.c_void_p]
     lib.macjd_mlp_forward.restype = ctypes.c_int

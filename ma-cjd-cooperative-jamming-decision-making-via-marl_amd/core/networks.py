@@ -209,10 +209,9 @@ class QMixer(nn.Module):
         """(w1_raw [M,J*Em], b1_raw [M,Em], wf_raw [M,Em], v_raw [M,1]) from the normalised state."""
         Hh, Em = self.hyper_hidden_dim, self.embed_dim
         out = self._first_layer(s)                              # [M, 2 Hh + 2 Em]
-        # split (backward = ONE cat) rather than slices (backward = a zero-fill + copy per slice plus adds); the
-        # three ReLUs are one launch over the first 2 Hh + Em columns, b1_raw is the remaining column block
-        pre, b1_raw = out.split([2 * Hh + Em, Em], dim=1)
-        h_w1, h_wf, h_v = F.relu(pre).split([Hh, Hh, Em], dim=1)
+        # the three ReLUs are one launch over the first 2 Hh + Em columns, b1_raw is the remaining column block; the
+        # backward of the whole split / ReLU / split is one launch too (ops.split_relu)
+        h_w1, h_wf, h_v, b1_raw = ops.split_relu(out, [Hh, Hh, Em], Em)
         w1_raw = ops.linear(h_w1, self.hyper_w_1[2].weight, self.hyper_w_1[2].bias)
         wf_raw = ops.linear(h_wf, self.hyper_w_final[2].weight, self.hyper_w_final[2].bias)
         v_raw = ops.linear(h_v, self.V[2].weight, self.V[2].bias)

@@ -905,3 +905,54 @@ extern "C" int macjd_rowdot(const macjd_rowdot_io* io, void* hip_stream) {
     if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
     return MACJD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Backward of the split / ReLU / split around the mixer's merged first layer: one elementwise launch.
+namespace macjd {
+
+__global__ void __launch_bounds__(256) splitrelu_backward_kernel(const macjd_splitrelu_bwd_io io, const int Cr) {
+    const int W = Cr + io.Cp;
+    const int64_t total = io.M * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / W;
+        const int c = (int)(i - m * W);
+        float v;
+        if (c >= Cr) {
+            v = io.g_pass ? io.g_pass[m * io.gp_ld + (c - Cr)] : 0.0f;
+        } else {
+            int k = 0, start = 0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                if (q + 1 < io.n_blocks && c >= start + io.width[k]) { start += io.width[k]; ++k; }
+            const float* gk = (k == 0) ? io.g[0] : (k == 1) ? io.g[1] : (k == 2) ? io.g[2] : io.g[3];
+            const int64_t ld = (k == 0) ? io.g_ld[0] : (k == 1) ? io.g_ld[1] : (k == 2) ? io.g_ld[2] : io.g_ld[3];
+            const float gv = gk ? gk[m * ld + (c - start)] : 0.0f;
+            v = (io.act[m * io.act_ld + c] > 0.0f) ? gv : 0.0f;
+        }
+        io.gout[m * io.gout_ld + c] = v;
+    }
+}
+
+}  // namespace macjd
+
+extern "C" int macjd_splitrelu_backward(const macjd_splitrelu_bwd_io* io, void* hip_stream) {
+    using namespace macjd;
+    if (!io || io->M < 0 || io->n_blocks < 1 || io->n_blocks > 4 || io->Cp < 0 || !io->act || !io->gout)
+        return set_nets_err(MACJD_EINVAL, "macjd_splitrelu_backward: bad argument");
+    int Cr = 0;
+    for (int k = 0; k < io->n_blocks; ++k) {
+        if (io->width[k] < 1) return set_nets_err(MACJD_EINVAL, "macjd_splitrelu_backward: bad block width");
+        if (io->g[k] && io->g_ld[k] < io->width[k]) return set_nets_err(MACJD_EINVAL, "macjd_splitrelu_backward: bad g_ld");
+        Cr += io->width[k];
+    }
+    if (io->act_ld < Cr || io->gout_ld < Cr + io->Cp || (io->g_pass && io->gp_ld < io->Cp))
+        return set_nets_err(MACJD_EINVAL, "macjd_splitrelu_backward: row stride smaller than the row");
+    if (io->M == 0) return MACJD_OK;
+    const int64_t total = io->M * (Cr + io->Cp);
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(splitrelu_backward_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0,
+                       (hipStream_t)hip_stream, *io, Cr);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
+    return MACJD_OK;
+}

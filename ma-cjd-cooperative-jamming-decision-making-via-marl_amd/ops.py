@@ -615,6 +615,64 @@ def layer_norm(x, weight, bias, eps: float = 1e-5):
     return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
 
 
+class _SplitRelu(torch.autograd.Function):
+    """(ReLU(x[:, :w0]), ReLU(x[:, w0:w0+w1]), ..., x[:, Cr:]) for a [M, Cr + Cp] matrix: the ReLU blocks are column
+    views of ONE activation buffer (one forward launch, as before); the backward writes the masked block gradients
+    and the pass-through gradient into the [M, Cr + Cp] result with ONE launch (autograd: cat + threshold_backward +
+    cat)."""
+
+    @staticmethod
+    def forward(ctx, x, widths, Cp):
+        Cr = sum(widths)
+        act = torch.relu(x[:, :Cr])                     # contiguous [M, Cr]
+        ctx.save_for_backward(act)
+        ctx.widths, ctx.Cp, ctx.shape = list(widths), int(Cp), tuple(x.shape)
+        outs = list(act.split(widths, dim=1))
+        if Cp:
+            outs.append(x[:, Cr:])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (act,) = ctx.saved_tensors
+        lib = _native.load()
+        M, W = ctx.shape
+        gout = torch.empty((M, W), dtype=torch.float32, device=act.device)
+        io = _native.SplitReluBwdIO()
+        io.M, io.n_blocks, io.Cp = M, len(ctx.widths), ctx.Cp
+        keep = []
+        for k, wk in enumerate(ctx.widths):
+            io.width[k] = wk
+            g = grads[k]
+            if g is not None:
+                g = _f32c(g)
+                keep.append(g)
+                setattr(io, f"g{k}", g.data_ptr())
+                io.g_ld[k] = g.stride(0)
+        if ctx.Cp and grads[len(ctx.widths)] is not None:
+            gp = _f32c(grads[len(ctx.widths)])
+            keep.append(gp)
+            io.g_pass, io.gp_ld = gp.data_ptr(), gp.stride(0)
+        io.act, io.act_ld, io.gout, io.gout_ld = act.data_ptr(), act.stride(0), gout.data_ptr(), gout.stride(0)
+        with torch.cuda.device(act.device):
+            _native.check(lib.macjd_splitrelu_backward(ctypes.byref(io), _stream(act)), "macjd_splitrelu_backward")
+        return gout, None, None
+
+
+def split_relu(x, relu_widths, pass_width: int):
+    """Column blocks of a 2-D tensor: ReLU on the first ``sum(relu_widths)`` columns (returned as blocks of those
+    widths), the last ``pass_width`` columns unchanged.  HIP device + autograd: fused backward (see _SplitRelu)."""
+    widths = [int(w) for w in relu_widths]
+    if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and torch.is_grad_enabled() and x.requires_grad \
+            and 1 <= len(widths) <= 4 and not torch.is_autocast_enabled():
+        return _SplitRelu.apply(x, widths, int(pass_width))
+    Cr = sum(widths)
+    outs = list(torch.relu(x[:, :Cr]).split(widths, dim=1))
+    if pass_width:
+        outs.append(x[:, Cr:])
+    return tuple(outs)
+
+
 def _rowdot_launch(x, w, b):
     lib = _native.load()
     x = _f32c(x.detach())

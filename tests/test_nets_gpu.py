@@ -771,3 +771,22 @@ def test_rowdot_kernel_single_output_linear(N, K):
         np.testing.assert_allclose(a.cpu().numpy(), r.cpu().numpy(), atol=1e-4 * max(1.0, float(r.abs().max())), rtol=1e-4)
     with torch.no_grad():
         assert torch.equal(ops.linear(x, W, b), y.detach())
+
+
+def test_split_relu_fused_backward_equals_autograd():
+    """ops.split_relu (one backward launch) == relu / split / slice under stock autograd, incl. an unused block."""
+    from macjd_amd import ops
+    g = torch.Generator().manual_seed(31)
+    M, widths, Cp = 3232, [128, 128, 64], 64
+    x = torch.randn(M, sum(widths) + Cp, generator=g).to(DEV).requires_grad_(True)
+    ups = [torch.randn(M, w, generator=g).to(DEV) for w in widths + [Cp]]
+    outs = ops.split_relu(x, widths, Cp)
+    assert [o.shape[1] for o in outs] == widths + [Cp]
+    (outs[0] * ups[0]).sum().add((outs[2] * ups[2]).sum()).add((outs[3] * ups[3]).sum()).backward()   # block 1 unused
+    x2 = x.detach().clone().requires_grad_(True)
+    Cr = sum(widths)
+    r = torch.relu(x2[:, :Cr]).split(widths, dim=1)
+    ((r[0] * ups[0]).sum() + (r[2] * ups[2]).sum() + (x2[:, Cr:] * ups[3]).sum()).backward()
+    assert torch.equal(x.grad, x2.grad)
+    for a, b in zip(outs[:3], r):
+        assert torch.equal(a, b)
