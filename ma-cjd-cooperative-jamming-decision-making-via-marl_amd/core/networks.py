@@ -126,7 +126,7 @@ class RNNAgent(nn.Module):
         # cat([h, onehot(a), P]) -> Linear -> ReLU -> Linear, exactly the reference's formulation (networks.py:171-176);
         # the one-hot is a compare + cast (any integer dtype), the Linears use the split-K weight gradient on a HIP device
         q_head_input = ops.qhead_input(hidden_state, idx, continuous_param, self.n_actions)   # [h, onehot(a), P]
-        return ops.linear(F.relu(ops.linear(q_head_input, l1.weight, l1.bias)), l2.weight, l2.bias)
+        return ops.linear(ops.linear_relu(q_head_input, l1.weight, l1.bias), l2.weight, l2.bias)
 
     def q_values_all_actions(self, hidden_state, continuous_params_all):
         """Q(h, a, P[:, a]) for all a at once, [N, A].  Inference path (no autograd): replaces the

@@ -334,9 +334,19 @@ ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 _MLP_LDS_FLOATS = 160 * 1024 // 4
 
 
+def _fused_relu_ok(x, w, b):
+    """hipBLASLt applies bias + ReLU in the GEMM epilogue through torch._addmm_activation: ONE kernel, bit-identical
+    to relu(linear(x)) on this stack (checked on MI355X for the path's shapes)."""
+    return (x.is_cuda and x.dim() == 2 and b is not None and x.dtype == torch.float32 and w.dtype == torch.float32
+            and not torch.is_autocast_enabled() and hasattr(torch, "_addmm_activation"))
+
+
 def mlp_reference(x, layers):
-    """layers = [(weight [out,in], bias [out], act), ...] evaluated with stock torch ops."""
+    """layers = [(weight [out,in], bias [out], act), ...] evaluated with library GEMMs / stock torch ops."""
     for w, b, act in layers:
+        if act == ACT_RELU and not torch.is_grad_enabled() and _fused_relu_ok(x, w, b):
+            x = torch._addmm_activation(b, x, w.t(), use_gelu=False)
+            continue
         x = F.linear(x, w, b)
         x = F.relu(x) if act == ACT_RELU else (torch.sigmoid(x) if act == ACT_SIGMOID else x)
     return x
@@ -713,6 +723,37 @@ def _rowdot_ok(x, weight):
     return (x.is_cuda and x.dim() == 2 and weight.shape[0] == 1 and x.dtype == torch.float32 and x.stride(-1) == 1
             and weight.shape[1] % 4 == 0 and 4 <= weight.shape[1] <= 1024 and x.shape[0] >= 1024
             and not torch.is_autocast_enabled())
+
+
+class _LinearReluSplitK(torch.autograd.Function):
+    """y = relu(x W^T + b) with the bias + ReLU in the GEMM epilogue (one forward kernel instead of two); backward:
+    mask by y > 0, library input gradient, split-K weight / bias gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        y = torch._addmm_activation(bias, x, weight.t(), use_gelu=False)
+        ctx.save_for_backward(x, weight, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        g = torch.ops.aten.threshold_backward(gy, y, 0.0)
+        gx = g.matmul(weight) if ctx.needs_input_grad[0] else None
+        gW, gb = linear_wgrad(g, x, want_bias=True)
+        return gx, gW, gb
+
+
+def linear_relu(x, weight, bias):
+    """relu(F.linear(x, weight, bias)); on a HIP device the ReLU rides in the GEMM epilogue (with autograd: the
+    split-K weight gradient as in ``linear``)."""
+    if _fused_relu_ok(x, weight, bias):
+        if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or bias.requires_grad):
+            if x.shape[0] >= 1024 and weight.shape[0] * weight.shape[1] <= 384 * 256 and x.stride(-1) == 1:
+                return _LinearReluSplitK.apply(x, weight, bias)
+            return F.relu(linear(x, weight, bias))
+        return torch._addmm_activation(bias, x, weight.t(), use_gelu=False)
+    return F.relu(linear(x, weight, bias))
 
 
 def linear(x, weight, bias=None):
