@@ -182,6 +182,11 @@ typedef struct macjd_wgrad_io {
 
 int64_t macjd_linear_wgrad_workspace_floats(int64_t K, int32_t M, int32_t N);
 int macjd_linear_wgrad(const macjd_wgrad_io* io, void* hip_stream);
+/* Up to MACJD_WGRAD_MAX_BATCH independent problems in ONE launch pair (all their (tile, chunk) partial products,
+   then all their chunk sums): same arithmetic and summation order as macjd_linear_wgrad per problem.  The learner's
+   backward pass defers its six weight gradients to one such call (they only feed .grad; nothing downstream waits). */
+#define MACJD_WGRAD_MAX_BATCH 8
+int macjd_linear_wgrad_many(const macjd_wgrad_io* ios, int32_t n, void* hip_stream);
 
 /*
  * Gather `n_rows` whole rows (episodes) of up to 8 tensors in ONE launch: dst_k[i, :] = src_k[idx[i], :] as raw

@@ -24,7 +24,7 @@ EXPORTS = [
     "macjd_env_reset", "macjd_env_step", "macjd_env_step_timed",
     "macjd_qhead_select", "macjd_gru_sequence", "macjd_mixer_tail_forward", "macjd_mixer_tail_backward",
     "macjd_mlp_forward", "macjd_td_loss", "macjd_clip_adam_step", "macjd_gather_rows",
-    "macjd_linear_wgrad", "macjd_linear_wgrad_workspace_floats", "macjd_qhead_input", "macjd_layernorm_forward", "macjd_gru_gates", "macjd_rowdot", "macjd_splitrelu_backward",
+    "macjd_linear_wgrad", "macjd_linear_wgrad_workspace_floats", "macjd_linear_wgrad_many", "macjd_qhead_input", "macjd_layernorm_forward", "macjd_gru_gates", "macjd_rowdot", "macjd_splitrelu_backward",
 ]
 
 
@@ -258,6 +258,8 @@ def load() -> ctypes.CDLL:
     lib.macjd_gather_rows.argtypes = [ctypes.POINTER(GatherIO), ctypes.c_void_p]
     lib.macjd_linear_wgrad.restype = ctypes.c_int
     lib.macjd_linear_wgrad.argtypes = [ctypes.POINTER(WgradIO), ctypes.c_void_p]
+    lib.macjd_linear_wgrad_many.restype = ctypes.c_int
+    lib.macjd_linear_wgrad_many.argtypes = [ctypes.POINTER(WgradIO), ctypes.c_int32, ctypes.c_void_p]
     lib.macjd_linear_wgrad_workspace_floats.restype = ctypes.c_int64
     lib.macjd_linear_wgrad_workspace_floats.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
     if lib.macjd_abi_version() != ABI_VERSION:

@@ -292,7 +292,8 @@ class QMixLearner:
             # the loss kernel also produces dL/dQ_tot: it seeds the backward pass directly (no ones-fill / multiply)
             loss, eval_mean, target_mean, gy = ops.td_loss_and_grad(
                 eval_q_tot, target_q_tot, st["reward"], st["terminated"], st["filled"], self.args.gamma, T - 1, 1)
-            eval_q_tot.backward(gy)
+            with ops.deferred_wgrad():   # the six weight gradients: one grouped launch pair after the chain
+                eval_q_tot.backward(gy)
         else:
             loss, eval_mean, target_mean = ops.td_loss_full(eval_q_tot, target_q_tot, st["reward"], st["terminated"],
                                                             st["filled"], self.args.gamma, T - 1, 1)

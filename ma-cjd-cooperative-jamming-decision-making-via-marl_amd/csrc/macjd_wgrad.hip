@@ -27,10 +27,19 @@ constexpr int WG_BM = 64, WG_BN = 64, WG_KC = 128, WG_PITCH = 80;
 
 __host__ __device__ inline int64_t wg_pad(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
-__global__ void __launch_bounds__(256) wgrad_partial_kernel(const macjd_wgrad_io io, const int Mp, const int Np) {
-    __shared__ float sA[WG_KC * WG_PITCH];   // gout chunk  [k][m]
-    __shared__ float sB[WG_KC * WG_PITCH];   // inp chunk   [k][n]
-    const int tn = blockIdx.x, tm = blockIdx.y, chunk = blockIdx.z;
+// fields of one problem as the partial-products body needs them (selected with compile-time indices from a batch)
+struct WgradProb {
+    int64_t K, gout_ld, inp_ld;
+    int M, N, Mp, Np, n_chunks;
+    const float* gout;
+    const float* inp;
+    float* workspace;
+    bool want_db;
+};
+
+__device__ __forceinline__ void wgrad_partial_body(const WgradProb& io, const int tn, const int tm, const int chunk,
+                                                   float* __restrict__ sA, float* __restrict__ sB) {
+    const int Mp = io.Mp, Np = io.Np;
     const int m0 = tm * WG_BM, n0 = tn * WG_BN;
     const int64_t k0 = (int64_t)chunk * WG_KC;
     const int tid = threadIdx.x;
@@ -96,12 +105,21 @@ __global__ void __launch_bounds__(256) wgrad_partial_kernel(const macjd_wgrad_io
                 ws[(int64_t)m * Np + n] = acc[a][b][r];
             }
     // ---- bias partial: column sums of the staged gout chunk (N-tile 0 only) ----
-    if (io.db && tn == 0 && tid < WG_BM) {
+    if (io.want_db && tn == 0 && tid < WG_BM) {
         float s = 0.0f;
 #pragma unroll 8
         for (int r = 0; r < WG_KC; ++r) s += sA[r * WG_PITCH + tid];
-        io.workspace[(int64_t)gridDim.z * Mp * Np + (int64_t)chunk * Mp + m0 + tid] = s;
+        io.workspace[(int64_t)io.n_chunks * Mp * Np + (int64_t)chunk * Mp + m0 + tid] = s;
     }
+}
+
+__global__ void __launch_bounds__(256) wgrad_partial_kernel(const macjd_wgrad_io io, const int Mp, const int Np) {
+    __shared__ float sA[WG_KC * WG_PITCH];   // gout chunk  [k][m]
+    __shared__ float sB[WG_KC * WG_PITCH];   // inp chunk   [k][n]
+    WgradProb p;
+    p.K = io.K; p.gout_ld = io.gout_ld; p.inp_ld = io.inp_ld; p.M = io.M; p.N = io.N; p.Mp = Mp; p.Np = Np;
+    p.n_chunks = (int)gridDim.z; p.gout = io.gout; p.inp = io.inp; p.workspace = io.workspace; p.want_db = io.db != nullptr;
+    wgrad_partial_body(p, blockIdx.x, blockIdx.y, blockIdx.z, sA, sB);
 }
 
 // Sum of the K-chunk partials, fixed order (deterministic).  8 lanes share one output element: lane s of the group adds
@@ -139,6 +157,88 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const macjd_wgrad_io 
     }
 }
 
+// ---- several problems in one launch pair (the backward pass of the learner defers its weight gradients) ----
+struct WgradBatch {
+    macjd_wgrad_io io[MACJD_WGRAD_MAX_BATCH];
+    int Mp[MACJD_WGRAD_MAX_BATCH], Np[MACJD_WGRAD_MAX_BATCH], chunks[MACJD_WGRAD_MAX_BATCH];
+    int tiles_n[MACJD_WGRAD_MAX_BATCH], tiles_m[MACJD_WGRAD_MAX_BATCH];
+    int64_t wg_start[MACJD_WGRAD_MAX_BATCH + 1];    // prefix of workgroups (tile x chunk work items) per problem
+    int64_t out_start[MACJD_WGRAD_MAX_BATCH + 1];   // prefix of reduce work items (M N + M outputs) per problem
+    int n;
+};
+
+// workgroup w works on problem p with wg_start[p] <= w < wg_start[p + 1]; the problem's fields are picked with
+// compile-time indices only (a run-time index into the by-value table would copy the ~1 KB struct to scratch)
+__global__ void __launch_bounds__(256) wgrad_partial_many_kernel(const WgradBatch b) {
+    __shared__ float sA[WG_KC * WG_PITCH];
+    __shared__ float sB[WG_KC * WG_PITCH];
+    const int64_t w = blockIdx.x;
+    WgradProb p;
+    int tiles_n = b.tiles_n[0], tiles_m = b.tiles_m[0];
+    int64_t start = 0;
+#define MACJD_PICK(q)                                                                                               \
+    p.K = b.io[q].K; p.gout_ld = b.io[q].gout_ld; p.inp_ld = b.io[q].inp_ld; p.M = b.io[q].M; p.N = b.io[q].N;       \
+    p.Mp = b.Mp[q]; p.Np = b.Np[q]; p.n_chunks = b.chunks[q]; p.gout = b.io[q].gout; p.inp = b.io[q].inp;            \
+    p.workspace = b.io[q].workspace; p.want_db = b.io[q].db != nullptr; tiles_n = b.tiles_n[q]; tiles_m = b.tiles_m[q]; \
+    start = b.wg_start[q];
+    MACJD_PICK(0)
+#pragma unroll
+    for (int q = 1; q < MACJD_WGRAD_MAX_BATCH; ++q) {
+        if (q < b.n && w >= b.wg_start[q]) { MACJD_PICK(q) }
+    }
+#undef MACJD_PICK
+    const int local = (int)(w - start);
+    const int tn = local % tiles_n, rest = local / tiles_n;
+    const int tm = rest % tiles_m, chunk = rest / tiles_m;
+    wgrad_partial_body(p, tn, tm, chunk, sA, sB);
+}
+
+__global__ void __launch_bounds__(256) wgrad_reduce_many_kernel(const WgradBatch b) {
+    const int sub = threadIdx.x & 7;
+    const int64_t groups_per_block = blockDim.x >> 3;
+    const int64_t total_all = b.out_start[b.n];
+    for (int64_t g = (int64_t)blockIdx.x * groups_per_block + (threadIdx.x >> 3); g < total_all;
+         g += (int64_t)gridDim.x * groups_per_block) {
+        int M = b.io[0].M, N = b.io[0].N, Mp = b.Mp[0], Np = b.Np[0], n_chunks = b.chunks[0];
+        int64_t start = 0, dw_ld = b.io[0].dw_ld;
+        const float* workspace = b.io[0].workspace;
+        float* dW = b.io[0].dW;
+        float* db = b.io[0].db;
+#pragma unroll
+        for (int q = 1; q < MACJD_WGRAD_MAX_BATCH; ++q) {
+            if (q < b.n && g >= b.out_start[q]) {
+                M = b.io[q].M; N = b.io[q].N; Mp = b.Mp[q]; Np = b.Np[q]; n_chunks = b.chunks[q];
+                start = b.out_start[q]; dw_ld = b.io[q].dw_ld; workspace = b.io[q].workspace; dW = b.io[q].dW; db = b.io[q].db;
+            }
+        }
+        const int64_t i = g - start;
+        const int64_t total = (int64_t)M * N;
+        float s = 0.0f;
+        if (i < total) {
+            const int m = (int)(i / N), n = (int)(i - (int64_t)m * N);
+            const float* ptr = workspace + (int64_t)m * Np + n;
+#pragma unroll 4
+            for (int c = sub; c < n_chunks; c += 8) s += ptr[(int64_t)c * Mp * Np];
+        } else if (db) {
+            const int m = (int)(i - total);
+            const float* ptr = workspace + (int64_t)n_chunks * Mp * Np + m;
+#pragma unroll 4
+            for (int c = sub; c < n_chunks; c += 8) s += ptr[(int64_t)c * Mp];
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (sub == 0) {
+            if (i < total) {
+                const int m = (int)(i / N), n = (int)(i - (int64_t)m * N);
+                dW[(int64_t)m * dw_ld + n] = s;
+            } else if (db) {
+                db[i - total] = s;
+            }
+        }
+    }
+}
+
 }  // namespace macjd
 
 extern "C" int64_t macjd_linear_wgrad_workspace_floats(int64_t K, int32_t M, int32_t N) {
@@ -164,5 +264,42 @@ extern "C" int macjd_linear_wgrad(const macjd_wgrad_io* io, void* hip_stream) {
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, s, *io, Mp, Np, (int)chunks);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_linear_wgrad: %s", hipGetErrorString(err));
+    return MACJD_OK;
+}
+
+extern "C" int macjd_linear_wgrad_many(const macjd_wgrad_io* ios, int32_t n, void* hip_stream) {
+    using namespace macjd;
+    if (!ios || n < 1 || n > MACJD_WGRAD_MAX_BATCH)
+        return set_err(MACJD_EINVAL, "%s", "macjd_linear_wgrad_many: 1..MACJD_WGRAD_MAX_BATCH problems");
+    WgradBatch b{};
+    b.n = n;
+    for (int p = 0; p < n; ++p) {
+        const macjd_wgrad_io* io = &ios[p];
+        if (io->K < 1 || io->M < 1 || io->N < 1 || !io->gout || !io->inp || !io->dW || !io->workspace)
+            return set_err(MACJD_EINVAL, "%s", "macjd_linear_wgrad_many: bad argument");
+        if (io->gout_ld < io->M || io->inp_ld < io->N || io->dw_ld < io->N)
+            return set_err(MACJD_EINVAL, "%s", "macjd_linear_wgrad_many: bad leading dimension");
+        b.io[p] = *io;
+        b.Mp[p] = (int)wg_pad(io->M, WG_BM);
+        b.Np[p] = (int)wg_pad(io->N, WG_BN);
+        b.chunks[p] = (int)((io->K + WG_KC - 1) / WG_KC);
+        b.tiles_n[p] = b.Np[p] / WG_BN;
+        b.tiles_m[p] = b.Mp[p] / WG_BM;
+        b.wg_start[p + 1] = b.wg_start[p] + (int64_t)b.tiles_n[p] * b.tiles_m[p] * b.chunks[p];
+        b.out_start[p + 1] = b.out_start[p] + (int64_t)io->M * io->N + io->M;
+    }
+    for (int p = n; p < MACJD_WGRAD_MAX_BATCH; ++p) {
+        b.wg_start[p + 1] = b.wg_start[n];
+        b.out_start[p + 1] = b.out_start[n];
+        b.tiles_n[p] = b.tiles_m[p] = 1;
+    }
+    if (b.wg_start[n] > 0x7fffffff) return set_err(MACJD_EUNSUPPORTED, "%s", "macjd_linear_wgrad_many: too many work items");
+    hipStream_t s = (hipStream_t)hip_stream;
+    hipLaunchKernelGGL(wgrad_partial_many_kernel, dim3((unsigned)b.wg_start[n]), dim3(256), 0, s, b);
+    const int64_t total = b.out_start[n];
+    const unsigned rblocks = (unsigned)((total + 31) / 32 < 4096 ? (total + 31) / 32 : 4096);
+    hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3(rblocks), dim3(256), 0, s, b);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_linear_wgrad_many: %s", hipGetErrorString(err));
     return MACJD_OK;
 }

@@ -790,3 +790,25 @@ def test_split_relu_fused_backward_equals_autograd():
     assert torch.equal(x.grad, x2.grad)
     for a, b in zip(outs[:3], r):
         assert torch.equal(a, b)
+
+
+def test_deferred_grouped_weight_gradients_equal_immediate():
+    """Inside ops.deferred_wgrad() the split-K weight gradients of several layers run as ONE partial-products launch +
+    ONE reduce launch at the end: bitwise the same results as the per-layer launches, for more problems than one
+    batch holds, with strided operands and with / without bias."""
+    from macjd_amd import ops
+    g = torch.Generator().manual_seed(21)
+    shapes = [(3232, 384, 46), (3232, 192, 128), (3232, 64, 128), (3232, 1, 64), (9696, 64, 74), (9696, 1, 64),
+              (1030, 7, 9), (1500, 33, 65), (2000, 64, 64), (1234, 5, 5)]
+    data = []
+    for K, M, N in shapes:
+        go = torch.randn(K, M + 4, generator=g).to(DEV)[:, 2:2 + M]
+        x = torch.randn(K, N, generator=g).to(DEV)
+        data.append((go, x))
+    ref = [ops.linear_wgrad(go, x, want_bias=(i % 3 != 2)) for i, (go, x) in enumerate(data)]
+    with ops.deferred_wgrad():
+        got = [ops.linear_wgrad(go, x, want_bias=(i % 3 != 2)) for i, (go, x) in enumerate(data)]
+    for (w1, b1), (w2, b2) in zip(ref, got):
+        assert torch.equal(w1, w2)
+        assert (b1 is None and b2 is None) or torch.equal(b1, b2)
+    assert ops._DEFERRED_WGRAD is None
