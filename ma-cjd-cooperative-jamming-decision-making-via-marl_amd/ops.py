@@ -511,9 +511,8 @@ class deferred_wgrad:
     """``with ops.deferred_wgrad(): loss.backward()`` — inside the context a split-K weight gradient launches nothing:
     the problem is recorded (its operands kept alive) and ALL recorded problems run as one partial-products launch +
     one reduce launch when the context exits (same arithmetic and summation order per problem).  They only feed
-    ``.grad`` and nothing in the backward pass waits for them, but launched one by one they sit on its serial chain
-    (12 launches, ~90 us of a ~170 us backward).  The gradient tensors handed to autograd are filled by the flush:
-    read them only after the context."""
+    ``.grad`` and nothing in the backward pass waits for them.  The gradient tensors handed to autograd are filled by
+    the flush: read them only after the context — and let autograd (or the caller) be their only owner until then."""
 
     def __enter__(self):
         global _DEFERRED_WGRAD
@@ -549,7 +548,10 @@ def linear_wgrad(gout, inp, want_bias=True):
     io.gout, io.gout_ld, io.inp, io.inp_ld = gout.data_ptr(), gout.stride(0), inp.data_ptr(), inp.stride(0)
     io.dW, io.dw_ld, io.db, io.workspace = dW.data_ptr(), dW.stride(0), (db.data_ptr() if want_bias else None), ws.data_ptr()
     if _DEFERRED_WGRAD is not None:
-        _DEFERRED_WGRAD.append((io, (dW, db, ws, gout, inp)))
+        # keep the OPERANDS and the workspace alive until the flush, but hold no reference to dW / db: autograd's
+        # AccumulateGrad only adopts a gradient tensor it is the sole owner of — with a second reference it would
+        # clone the still unfilled buffer into .grad right away (the flush would then fill a tensor nobody reads)
+        _DEFERRED_WGRAD.append((io, (ws, gout, inp)))
         return dW, db
     with torch.cuda.device(gout.device):
         _native.check(lib.macjd_linear_wgrad(ctypes.byref(io), _stream(gout)), "macjd_linear_wgrad")

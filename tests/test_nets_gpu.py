@@ -812,3 +812,36 @@ def test_deferred_grouped_weight_gradients_equal_immediate():
         assert torch.equal(w1, w2)
         assert (b1 is None and b2 is None) or torch.equal(b1, b2)
     assert ops._DEFERRED_WGRAD is None
+
+
+def test_deferred_weight_gradients_reach_dot_grad_exactly():
+    """Through real autograd: parameters' .grad after a backward inside ops.deferred_wgrad() are bitwise those of an
+    ordinary backward, also when the buffers held other values before (a replayed graph reuses them), and no copy of
+    an unfilled buffer is taken (AccumulateGrad must adopt the tensors the flush fills)."""
+    from macjd_amd import ops
+    g = torch.Generator().manual_seed(5)
+    K = 3232
+    x = torch.randn(K, 46, generator=g).to(DEV)
+    W1 = (0.2 * torch.randn(128, 46, generator=g)).to(DEV).requires_grad_(True)
+    b1 = torch.zeros(128, device=DEV, requires_grad=True)
+    W2 = (0.2 * torch.randn(1, 128, generator=g)).to(DEV).requires_grad_(True)
+    b2 = torch.zeros(1, device=DEV, requires_grad=True)
+    params = [W1, b1, W2, b2]
+
+    def run(deferred, scale):
+        for p_ in params:
+            p_.grad = None
+        y = ops.linear(ops.linear_relu(x * scale, W1, b1), W2, b2)
+        up = torch.ones_like(y)
+        if deferred:
+            with ops.deferred_wgrad():
+                y.backward(up)
+        else:
+            y.backward(up)
+        return [p_.grad.clone() for p_ in params]
+
+    for scale in (1.0, -0.7, 2.5):      # different gradients each time: stale buffers would show
+        ref = run(False, scale)
+        got = run(True, scale)
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b)
