@@ -585,7 +585,12 @@ __global__ void __launch_bounds__(256) adam_sqnorm_kernel(const macjd_adam_io io
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) io.partials[blockIdx.x] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+    if (threadIdx.x == 0) {
+        io.partials[blockIdx.x] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+        // the optimiser's step counter advances HERE: nothing in this kernel reads it, and the update kernel that follows
+        // reads the advanced value (a third one-thread launch used to do this after the update)
+        if (blockIdx.x == 0) io.step[0] += 1.0f;
+    }
 }
 
 __global__ void __launch_bounds__(256) adam_update_kernel(const macjd_adam_io io, const int n_partials) {
@@ -600,7 +605,7 @@ __global__ void __launch_bounds__(256) adam_update_kernel(const macjd_adam_io io
     const float total_norm = sqrtf(s_tot);
     float coef = io.max_norm / (total_norm + 1e-6f);
     coef = coef < 1.0f ? coef : 1.0f;
-    const float step = io.step[0] + 1.0f;
+    const float step = io.step[0];   // already advanced by adam_sqnorm_kernel
     const float bc1 = 1.0f - powf(io.beta1, step);
     const float bc2 = 1.0f - powf(io.beta2, step);
     const float step_size = io.lr / bc1;
@@ -619,8 +624,6 @@ __global__ void __launch_bounds__(256) adam_update_kernel(const macjd_adam_io io
     if (blockIdx.x == 0 && threadIdx.x == 0) io.grad_norm[0] = total_norm;
     // the step counter is bumped by a trailing single-thread launch (all blocks must have read the old value)
 }
-
-__global__ void adam_bump_step_kernel(float* step) { step[0] += 1.0f; }
 
 __global__ void __launch_bounds__(256) gather_rows_kernel(const macjd_gather_io io) {
     const int k = blockIdx.y;       // tensor
@@ -653,7 +656,6 @@ extern "C" int macjd_clip_adam_step(const macjd_adam_io* io, void* hip_stream) {
     if (blocks > ADAM_BLOCKS) blocks = ADAM_BLOCKS;
     hipLaunchKernelGGL(adam_sqnorm_kernel, dim3(blocks), dim3(256), 0, s, *io);
     hipLaunchKernelGGL(adam_update_kernel, dim3(blocks), dim3(256), 0, s, *io, blocks);
-    hipLaunchKernelGGL(adam_bump_step_kernel, dim3(1), dim3(1), 0, s, io->step);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
     return MACJD_OK;
