@@ -331,15 +331,18 @@ def test_gru_sequence_kernel(H, B, T, J):
     assert torch.equal(single, got[0])
 
 
-def test_graphed_train_equals_eager_train():
+@pytest.mark.parametrize("T,N,B,steps", [(12, 40, 8, 7), (100, 48, 32, 4)])
+def test_graphed_train_equals_eager_train(T, N, B, steps):
     """HIP-graph replay of the learner step == the eager step: same sampled episodes -> same losses and
-    the same weights after several updates incl. a target sync."""
+    the same weights after several updates incl. a target sync.  The second size is the benchmark's (32 episodes x
+    101 steps x 3 agents = 9696 rows): only there do the split-K / grouped weight gradients, the row-dot and the
+    fused-ReLU paths engage (they need >= 1024 rows), and every step samples different episodes, so a gradient that
+    arrived one replay late would show in grad_norm."""
     from macjd_amd.core.mac import BasicMAC
     from macjd_amd.core.qmix import QMixLearner
     from macjd_amd.utils.replay_buffer import EpisodeReplayBuffer
     from tests_golden_helpers import synthetic_batch
     g, d = load("3j4r_h64")
-    T, N, B = 12, 40, 8
     def build():
         args = _gpu_args(d, episode_limit=T, buffer_size=N, batch_size=B, target_update_interval=3)
         with quiet():
@@ -359,14 +362,14 @@ def test_graphed_train_equals_eager_train():
     mac_g, graphed, buf_g = build()
     graphed.enable_graphs(buf_g, B)   # warm-up updates are undone in place: both start from the same state
     rng = np.random.default_rng(1)
-    for step in range(7):
+    for step in range(steps):
         idx = rng.choice(N, B, replace=False)
         se = eager.train(buf_e.sample(B, indices=idx), {})
         sg = graphed.train_from_buffer(indices=idx)
         for k in se:
             assert sg[k] == pytest.approx(se[k], rel=1e-4, abs=1e-6), (step, k)
-    assert graphed.train_step == eager.train_step == 7 and graphed.last_target_update_step == 6
-    # weights after 7 Adam steps (lr 5e-4): Adam's m / sqrt(v) amplifies summation-order noise of near-zero gradient
+    assert graphed.train_step == eager.train_step == steps and graphed.last_target_update_step == 3 * (steps // 3)
+    # weights after the Adam steps (lr 5e-4): Adam's m / sqrt(v) amplifies summation-order noise of near-zero gradient
     # entries (the graphed path reduces over full-length rows), hence 2e-5 rather than float epsilon
     for (k, a), b in zip(mac_e.agent.state_dict().items(), mac_g.agent.state_dict().values()):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-5, rtol=0, err_msg=k)
