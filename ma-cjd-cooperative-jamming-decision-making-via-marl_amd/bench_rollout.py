@@ -31,6 +31,41 @@ def make_args(sc, hidden, device, batch_size=32, buffer_size=None, batch_envs=40
         device=str(device), use_cuda=True, seed=seed)
 
 
+def _make_step_fn(cli, runner, learner, buf, args, T, mode, use_graphs, tails):
+    """The per-step schedule of the benchmark (no device code here: tests drive it with a fake runner)."""
+    state = {"graphed_episode": False}
+
+    def step_fn(i):
+        # Episodes are aligned to the regions the caller times: the warm-up steps are their own run of episodes and
+        # the timed steps start a fresh episode batch at step `warmup`.  A whole episode batch (reset + T batched
+        # steps) is ONE graph launch; the partial episode at the end of a region replays its own shorter graph.
+        # Without the alignment a graph launched during warm-up would do the work of later, timed, steps before
+        # the clock starts.
+        if i < cli.warmup:
+            j, region = i, cli.warmup
+        else:
+            j, region = i - cli.warmup, cli.steps
+        t = j % T
+        if t == 0:
+            left = region - j
+            state["graphed_episode"] = use_graphs and (left >= T or left in tails)
+            if state["graphed_episode"]:
+                runner.rollout_graphed(None if left >= T else left)
+            else:
+                runner.begin_episodes()
+        if not state["graphed_episode"]:
+            runner.step(t)
+        if t == T - 1:
+            runner.end_episodes()
+        if mode == "train":
+            if use_graphs:
+                learner.train_from_buffer(sync_stats=False)
+            else:
+                learner.train(buf.sample(args.batch_size), None, sync_stats=False)
+
+    return step_fn
+
+
 def make_step(cli, sc, env, dev, rank, world, mode):
     from .core.mac import BasicMAC
     from .core.qmix import QMixLearner
@@ -70,35 +105,7 @@ def make_step(cli, sc, env, dev, rank, world, mode):
         tails = {r % T for r in (cli.warmup, cli.steps) if r % T}
         for n in sorted(tails):
             runner.enable_graph(n_steps=n)
-    state = {"graphed_episode": False}
-
-    def step_fn(i):
-        # Episodes are aligned to the regions the caller times: the warm-up steps are their own run of episodes and
-        # the timed steps start a fresh episode batch at step `warmup`.  A whole episode batch (reset + T batched
-        # steps) is ONE graph launch; the partial episode at the end of a region replays its own shorter graph.
-        # Without the alignment a graph launched during warm-up would do the work of later, timed, steps before
-        # the clock starts.
-        if i < cli.warmup:
-            j, region = i, cli.warmup
-        else:
-            j, region = i - cli.warmup, cli.steps
-        t = j % T
-        if t == 0:
-            left = region - j
-            state["graphed_episode"] = use_graphs and (left >= T or left in tails)
-            if state["graphed_episode"]:
-                runner.rollout_graphed(None if left >= T else left)
-            else:
-                runner.begin_episodes()
-        if not state["graphed_episode"]:
-            runner.step(t)
-        if t == T - 1:
-            runner.end_episodes()
-        if mode == "train":
-            if use_graphs:
-                learner.train_from_buffer(sync_stats=False)
-            else:
-                learner.train(buf.sample(args.batch_size), None, sync_stats=False)
+    step_fn = _make_step_fn(cli, runner, learner if mode == "train" else None, buf, args, T, mode, use_graphs, tails)
 
     extra = {"hidden": cli.hidden, "train_batch_episodes": args.batch_size if mode == "train" else 0,
              "train_calls_per_step": 1 if mode == "train" else 0, "hip_graphs": bool(use_graphs), "gemm_tuning": bool(gemm_tuning),

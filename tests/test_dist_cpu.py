@@ -96,3 +96,52 @@ def test_two_rank_gradient_allreduce(tmp_path):
     np.testing.assert_allclose(learner.grad_vector().numpy(), g0, rtol=2e-4, atol=1e-6)
     flat = torch.cat([p.detach().reshape(-1) for p in learner._trainable()]).numpy()
     np.testing.assert_allclose(flat, np.load(tmp_path / "w_rank0.npy"), rtol=0, atol=2e-6)
+
+
+def test_bench_step_accounting_is_region_aligned():
+    """bench_rollout.make_step's schedule: episodes restart at the warm-up / timed boundary, whole episodes replay the
+    full graph, the partial episode at the end of a region replays its own shorter graph, so the steps a caller times
+    do exactly the work of those steps (a whole-episode graph launched in warm-up used to pre-pay timed steps)."""
+    from types import SimpleNamespace
+    import macjd_amd.bench_rollout as br
+
+    T = 100
+
+    class FakeRunner:
+        def __init__(self):
+            self.log = []
+
+        def rollout_graphed(self, n=None):
+            self.log.append(("graph", T if n is None else n))
+
+        def begin_episodes(self):
+            self.log.append(("begin", 0))
+
+        def step(self, t):
+            self.log.append(("step", t))
+
+        def end_episodes(self):
+            self.log.append(("end", 0))
+
+    def schedule(warmup, steps):
+        runner = FakeRunner()
+        cli = SimpleNamespace(warmup=warmup, steps=steps)
+        step_fn = br._make_step_fn(cli, runner, None, None, None, T, "rollout", True,
+                                   {r % T for r in (warmup, steps) if r % T})
+        per_step = []
+        for i in range(warmup + steps):
+            n0 = len(runner.log)
+            step_fn(i)
+            per_step.append(runner.log[n0:])
+        return per_step
+
+    for warmup, steps in ((20, 200), (100, 1000), (2, 5), (30, 250), (0, 100)):
+        per_step = schedule(warmup, steps)
+        timed = per_step[warmup:]
+        work = sum(n for ev in timed for kind, n in ev if kind == "graph") + sum(1 for ev in timed for kind, _ in ev if kind == "step")
+        assert work == steps, (warmup, steps, work)                       # timed steps do exactly their own work
+        pre = (sum(n for ev in per_step[:warmup] for kind, n in ev if kind == "graph")
+               + sum(1 for ev in per_step[:warmup] for kind, _ in ev if kind == "step"))
+        assert pre == warmup
+        assert not any(kind == "step" for ev in per_step for kind, _ in ev)   # every step comes from a graph
+        assert sum(1 for ev in timed for kind, _ in ev if kind == "end") == steps // T
