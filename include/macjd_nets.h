@@ -263,6 +263,9 @@ typedef struct macjd_mlp_io {
 
 /* One launch, no workspace: the weights are read in torch's own [out, in] layout (LDS-DMA into padded LDS rows). */
 int macjd_mlp_forward(const macjd_mlp_io* io, void* hip_stream);
+/* Two independent chains in ONE launch (workgroups are split between them): the actor chain and the fc1 -> W_ih chain
+   of the rollout step over the same observation rows, or the eval and target actors of the learner. */
+int macjd_mlp_forward_pair(const macjd_mlp_io* io0, const macjd_mlp_io* io1, void* hip_stream);
 
 /*
  * Backward of "ReLU on the first Cr columns of a [M, Cr + Cp] matrix, pass the last Cp columns through, hand the

@@ -23,7 +23,7 @@ EXPORTS = [
     "macjd_scenario_create", "macjd_scenario_destroy", "macjd_scenario_dims",
     "macjd_env_reset", "macjd_env_step", "macjd_env_step_timed",
     "macjd_qhead_select", "macjd_gru_sequence", "macjd_mixer_tail_forward", "macjd_mixer_tail_backward",
-    "macjd_mlp_forward", "macjd_td_loss", "macjd_clip_adam_step", "macjd_gather_rows",
+    "macjd_mlp_forward", "macjd_mlp_forward_pair", "macjd_td_loss", "macjd_clip_adam_step", "macjd_gather_rows",
     "macjd_linear_wgrad", "macjd_linear_wgrad_workspace_floats", "macjd_linear_wgrad_many", "macjd_qhead_input", "macjd_layernorm_forward", "macjd_gru_gates", "macjd_rowdot", "macjd_splitrelu_backward",
 ]
 
@@ -248,6 +248,8 @@ def load() -> ctypes.CDLL:
     lib.macjd_splitrelu_backward.argtypes = [ctypes.POINTER(SplitReluBwdIO), ctypes.c_void_p]
     lib.macjd_rowdot.restype = ctypes.c_int
     lib.macjd_rowdot.argtypes = [ctypes.POINTER(RowdotIO), ctypes.c_void_p]
+    lib.macjd_mlp_forward_pair.restype = ctypes.c_int
+    lib.macjd_mlp_forward_pair.argtypes = [ctypes.POINTER(MlpIO), ctypes.POINTER(MlpIO), ctypes.c_void_p]
     lib.macjd_mlp_forward.restype = ctypes.c_int
     lib.macjd_mlp_forward.argtypes = [ctypes.POINTER(MlpIO), ctypes.c_void_p]
     lib.macjd_td_loss.restype = ctypes.c_int

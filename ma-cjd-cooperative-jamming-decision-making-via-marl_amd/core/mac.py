@@ -95,12 +95,11 @@ class BasicMAC:
 
     def forward(self, agent_inputs_reshaped, hidden_states, h_out2=None):
         """-> (h' [N, H], continuous params for all actions [N, A])  (mac.py:168-187)."""
-        if h_out2 is not None and agent_inputs_reshaped.is_cuda and not torch.is_grad_enabled():
-            h_out = self.agent.forward(agent_inputs_reshaped, hidden_states, h_out2=h_out2)
-        else:
-            h_out = self.agent.forward(agent_inputs_reshaped, hidden_states)
-            if h_out2 is not None:
-                h_out2.view(h_out.shape).copy_(h_out.detach())
+        if not torch.is_grad_enabled():
+            return self.agent.step_forward(agent_inputs_reshaped, hidden_states, h_out2=h_out2)
+        h_out = self.agent.forward(agent_inputs_reshaped, hidden_states)
+        if h_out2 is not None:
+            h_out2.view(h_out.shape).copy_(h_out.detach())
         return h_out, self.agent.actor_forward(agent_inputs_reshaped)
 
     def init_hidden(self, batch_size):

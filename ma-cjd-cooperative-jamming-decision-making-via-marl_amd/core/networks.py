@@ -93,6 +93,30 @@ class RNNAgent(nn.Module):
             h_in = h_in.to(x.device)
         return self.rnn(x.contiguous(), h_in.contiguous())
 
+    def actor_layers(self):
+        a = self.actor
+        return [(a[0].weight, a[0].bias, ops.ACT_RELU), (a[2].weight, a[2].bias, ops.ACT_RELU),
+                (a[4].weight, a[4].bias, ops.ACT_SIGMOID)]
+
+    def gi_layers(self):
+        return [(self.fc1.weight, self.fc1.bias, ops.ACT_RELU), (self.rnn.weight_ih, self.rnn.bias_ih, ops.ACT_NONE)]
+
+    def step_forward(self, agent_inputs, h_in, h_out2=None):
+        """One rollout step of the agent: (h' [N, H], continuous params for all actions [N, A]).  On the HIP inference
+        path the actor chain and the fc1 -> W_ih chain — both read the same observation rows — are ONE launch."""
+        x = agent_inputs
+        if self._fused_ok(x) and x.dim() == 2 and self.fused_actor and self.fused_gi_step:
+            params, gi = ops.mlp_forward_pair(x, self.actor_layers(), x, self.gi_layers())
+            gh = F.linear(h_in.to(gi.device), self.rnn.weight_hh, self.rnn.bias_hh)
+            return ops.gru_gates(gi, gh, h_in, out2=h_out2), params
+        if h_out2 is not None and self._fused_ok(x):
+            h = self.forward(x, h_in, h_out2=h_out2)
+        else:
+            h = self.forward(x, h_in)
+            if h_out2 is not None:
+                h_out2.view(h.shape).copy_(h.detach())
+        return h, self.actor_forward(x)
+
     def actor_forward(self, inputs):
         """Continuous parameter for EVERY discrete action, [N, A] in (0,1)  (networks.py:116-129)."""
         if self.fused_actor and self._fused_ok(inputs):

@@ -247,8 +247,11 @@ class QMixLearner:
             return [F.linear(h.reshape(n, H), hd[0][:, :H], m.agent.fc2_q_head[0].bias)
                     for m, h, hd in zip(macs, h_alls, heads)]
 
-        def actor_chains():
-            return [m.agent.actor_forward(rows) for m in macs]                                  # networks.py:127
+        def actor_chains():                                                                     # networks.py:127
+            a0, a1 = macs[0].agent, macs[1].agent
+            if rows.is_cuda and a0.fused_actor and a1.fused_actor:   # both controllers' actor chains: one launch
+                return list(ops.mlp_forward_pair(rows, a0.actor_layers(), rows, a1.actor_layers()))
+            return [m.agent.actor_forward(rows) for m in macs]
 
         def target_q_tot_of(bases, params, hyper):
             # a* = argmax_a Q_eval (no mask, qmix.py:138-143), Q_target(a*) (qmix.py:147): two launches, [B,T+1,J]

@@ -263,7 +263,9 @@ __device__ __forceinline__ void mlp_layer_dispatch(int nt, float* strip, int lda
     }
 }
 
-__global__ void __launch_bounds__(64 * MLP_WAVES) mlp_forward_kernel(const macjd_mlp_io io, const MlpGeom g) {
+// the whole chain for the 64-row tiles block, block + n_blocks, ... of one problem (one copy of the code: the
+// single-problem kernel and the two-problem kernel both call it)
+__device__ __forceinline__ void mlp_forward_body(const macjd_mlp_io& io, const MlpGeom& g, const int block, const int n_blocks) {
     extern __shared__ float lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave: scalar
     const int lda = g.lda;
@@ -277,7 +279,7 @@ __global__ void __launch_bounds__(64 * MLP_WAVES) mlp_forward_kernel(const macjd
     }
     const int K0 = io.dims[0], K0p = mlp_k16(K0);
     const int64_t n_tiles = (io.n_rows + 63) / 64;
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int64_t tile = block; tile < n_tiles; tile += n_blocks) {
         const int64_t row0 = tile * 64 + wave * 16;
         // this wave's 16 input rows: LDS-DMA straight into the strip; missing rows and pad columns are zeroed
         if (!(MLP_ABL & 2)) {
@@ -316,15 +318,30 @@ __global__ void __launch_bounds__(64 * MLP_WAVES) mlp_forward_kernel(const macjd
     mlp_dma_wait();   // a workgroup without tiles must still drain its DMA before exit
 }
 
+__global__ void __launch_bounds__(64 * MLP_WAVES) mlp_forward_kernel(const macjd_mlp_io io, const MlpGeom g) {
+    mlp_forward_body(io, g, blockIdx.x, gridDim.x);
+}
+
+// two independent chains in one launch: workgroups [0, split) run problem 0, the rest problem 1 (e.g. the actor chain
+// and the fc1 -> W_ih chain of the rollout step over the same rows, or the eval and target actors of the learner)
+__global__ void __launch_bounds__(64 * MLP_WAVES) mlp_forward_pair_kernel(const macjd_mlp_io io0, const MlpGeom g0,
+                                                                          const macjd_mlp_io io1, const MlpGeom g1,
+                                                                          const int split) {
+    if ((int)blockIdx.x < split) mlp_forward_body(io0, g0, blockIdx.x, split);
+    else mlp_forward_body(io1, g1, blockIdx.x - split, gridDim.x - split);
+}
+
 }  // namespace macjd
 
-extern "C" int macjd_mlp_forward(const macjd_mlp_io* io, void* hip_stream) {
+// validates one problem and fills its LDS geometry; *lds_floats = strips + weight images
+static int mlp_prepare(const macjd_mlp_io* io, macjd::MlpGeom* gp, size_t* lds_floats) {
     using namespace macjd;
     if (!io) return set_err(MACJD_EINVAL, "%s", "macjd_mlp_forward: NULL io");
     const int L = io->n_layers;
     if (L < 1 || L > 3 || io->n_rows < 0 || !io->x || !io->y)
         return set_err(MACJD_EINVAL, "%s", "macjd_mlp_forward: bad n_layers / n_rows / pointers");
-    MlpGeom g{};
+    MlpGeom& g = *gp;
+    g = MlpGeom{};
     int total = 0, biggest = 0, widest = 0;
     for (int l = 0; l < L; ++l) {
         const int K = io->dims[l], N = io->dims[l + 1];
@@ -348,7 +365,6 @@ extern "C" int macjd_mlp_forward(const macjd_mlp_io* io, void* hip_stream) {
     // x_ld == 0 is a broadcast input (every row the same vector, e.g. the static observation): fine to read
     if ((io->x_ld != 0 && io->x_ld < io->dims[0]) || io->y_ld < io->dims[L])
         return set_err(MACJD_EINVAL, "%s", "macjd_mlp_forward: row stride smaller than the row");
-    if (io->n_rows == 0) return MACJD_OK;
     g.vec16[3] = (io->dims[0] % 4 == 0) && (io->x_ld % 4 == 0) && (((uintptr_t)io->x) % 16 == 0);
     g.lda = mlp_pitch(mlp_k16(widest));
     const int strips_f = MLP_WAVES * 16 * g.lda;
@@ -359,7 +375,43 @@ extern "C" int macjd_mlp_forward(const macjd_mlp_io* io, void* hip_stream) {
             return set_err(MACJD_EUNSUPPORTED, "%s", "macjd_mlp_forward: one layer's weights exceed the LDS budget");
         for (int l = 0; l < L; ++l) g.off[l] = 0;
     }
-    const size_t lds_bytes = (size_t)(strips_f + (g.resident ? total : biggest)) * 4;
+    *lds_floats = (size_t)strips_f + (size_t)(g.resident ? total : biggest);
+    return MACJD_OK;
+}
+
+extern "C" int macjd_mlp_forward_pair(const macjd_mlp_io* io0, const macjd_mlp_io* io1, void* hip_stream) {
+    using namespace macjd;
+    MlpGeom g0, g1;
+    size_t f0 = 0, f1 = 0;
+    int rc = mlp_prepare(io0, &g0, &f0);
+    if (rc != MACJD_OK) return rc;
+    rc = mlp_prepare(io1, &g1, &f1);
+    if (rc != MACJD_OK) return rc;
+    if (io0->n_rows == 0 || io1->n_rows == 0)
+        return set_err(MACJD_EINVAL, "%s", "macjd_mlp_forward_pair: both problems need rows (use macjd_mlp_forward)");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)mlp_forward_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_BYTES);
+        attr_set = true;
+    }
+    const int64_t t0 = (io0->n_rows + 63) / 64, t1 = (io1->n_rows + 63) / 64;
+    const int b0 = (int)(t0 < 256 ? t0 : 256), b1 = (int)(t1 < 256 ? t1 : 256);
+    const size_t lds_bytes = (f0 > f1 ? f0 : f1) * 4;
+    hipLaunchKernelGGL(mlp_forward_pair_kernel, dim3((unsigned)(b0 + b1)), dim3(64 * MLP_WAVES), lds_bytes,
+                       (hipStream_t)hip_stream, *io0, g0, *io1, g1, b0);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_mlp_forward_pair: %s", hipGetErrorString(err));
+    return MACJD_OK;
+}
+
+extern "C" int macjd_mlp_forward(const macjd_mlp_io* io, void* hip_stream) {
+    using namespace macjd;
+    MlpGeom g;
+    size_t lds_floats = 0;
+    const int rc = mlp_prepare(io, &g, &lds_floats);
+    if (rc != MACJD_OK) return rc;
+    if (io->n_rows == 0) return MACJD_OK;
+    const size_t lds_bytes = lds_floats * 4;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)mlp_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_BYTES);

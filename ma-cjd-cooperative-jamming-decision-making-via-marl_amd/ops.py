@@ -399,6 +399,40 @@ def mlp_forward(x, layers):
     return y
 
 
+def _mlp_io(x, layers, keep):
+    dims = [layers[0][0].shape[1]] + [w.shape[0] for w, _, _ in layers]
+    x = _f32c(x.detach())
+    if x.dim() != 2:
+        x = x.reshape(-1, dims[0])
+    y = torch.empty((x.shape[0], dims[-1]), dtype=torch.float32, device=x.device)
+    io = _native.MlpIO()
+    io.n_rows, io.n_layers = x.shape[0], len(layers)
+    for l, (w, b, act) in enumerate(layers):
+        w, b = w.detach().float().contiguous(), b.detach().float().contiguous()
+        keep += [w, b]
+        io.dims[l], io.W[l], io.b[l], io.act[l] = dims[l], w.data_ptr(), b.data_ptr(), int(act)
+    io.dims[len(layers)] = dims[-1]
+    io.x, io.x_ld, io.y, io.y_ld = x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0)
+    keep.append(x)
+    return io, y, dims
+
+
+def mlp_forward_pair(x0, layers0, x1, layers1):
+    """Two independent dense chains (see mlp_forward) in ONE launch on a HIP device: -> (y0, y1).  Falls back to two
+    separate evaluations when either chain is outside the kernel's limits or the tensors live on the host."""
+    d0 = [layers0[0][0].shape[1]] + [w.shape[0] for w, _, _ in layers0]
+    d1 = [layers1[0][0].shape[1]] + [w.shape[0] for w, _, _ in layers1]
+    if not (x0.is_cuda and x1.is_cuda and mlp_supported(d0) and mlp_supported(d1)) or x0.numel() == 0 or x1.numel() == 0:
+        return mlp_forward(x0, layers0), mlp_forward(x1, layers1)
+    lib = _native.load()
+    keep = []
+    io0, y0, _ = _mlp_io(x0, layers0, keep)
+    io1, y1, _ = _mlp_io(x1, layers1, keep)
+    with torch.cuda.device(x0.device):
+        _native.check(lib.macjd_mlp_forward_pair(ctypes.byref(io0), ctypes.byref(io1), _stream(x0)), "macjd_mlp_forward_pair")
+    return y0, y1
+
+
 # ---------------------------------------------------------------------------------------------
 # TD target + masked loss (reference core/qmix.py:155,190-194)
 def td_loss_reference(y, tq, reward, terminated, filled, gamma):

@@ -848,3 +848,22 @@ def test_deferred_weight_gradients_reach_dot_grad_exactly():
         got = run(True, scale)
         for a, b in zip(ref, got):
             assert torch.equal(a, b)
+
+
+def test_mlp_forward_pair_equals_two_single_launches():
+    """Two independent dense chains in one launch == the two single launches, bitwise (actor + fc1/W_ih chains over
+    the same rows; different row counts; one chain with weights staged per layer)."""
+    from macjd_amd import ops
+    g = torch.Generator().manual_seed(77)
+
+    def chain(dims, acts):
+        return [((torch.randn(dims[i + 1], dims[i], generator=g) / np.sqrt(dims[i])).to(DEV),
+                 (0.1 * torch.randn(dims[i + 1], generator=g)).to(DEV), acts[i]) for i in range(len(acts))]
+
+    x = torch.randn(12288, 46, generator=g).to(DEV)
+    x2 = torch.randn(1000, 184, generator=g).to(DEV)
+    cases = [((x, chain((46, 128, 128, 9), (1, 1, 2))), (x, chain((46, 64, 192), (1, 0)))),
+             ((x[:777], chain((46, 128, 128, 9), (1, 1, 2))), (x2, chain((184, 128, 128, 33), (1, 1, 2))))]
+    for (xa, la), (xb, lb) in cases:
+        ya, yb = ops.mlp_forward_pair(xa, la, xb, lb)
+        assert torch.equal(ya, ops.mlp_forward(xa, la)) and torch.equal(yb, ops.mlp_forward(xb, lb))
