@@ -233,9 +233,28 @@ typedef struct macjd_layernorm_io {
     float* y;        int64_t y_ld;
     float* mean;          /* [M], optional */
     float* rstd;          /* [M], optional */
+    float* xhat;     int64_t xhat_ld;   /* optional [M, S]: the normalised input (x - mean) rstd, before gamma / beta */
 } macjd_layernorm_io;
 
 int macjd_layernorm_forward(const macjd_layernorm_io* io, void* hip_stream);
+
+/*
+ * Gradients of a LayerNorm's gamma / beta when the normalised tensor feeds ONE Linear layer y = s W^T + b,
+ * s = xhat gamma + beta (QMixer.state_norm -> the merged first hyper-network layer), from quantities the weight-
+ * gradient pass already has:  dbeta[k] = sum_c gb[c] W[c,k],  dgamma[k] = sum_c W[c,k] G[c,k]  with gb = column sums
+ * of the layer's output gradient and G = gout^T xhat ([C, K], one more split-K problem).  Replaces the [M, K]
+ * input-gradient GEMM + the two reduction launches of native_layer_norm_backward.
+ */
+typedef struct macjd_lnparam_io {
+    int32_t C, K;                          /* Linear: C outputs, K inputs (= LayerNorm width) */
+    const float* W;   int64_t w_ld;        /* [C, K] */
+    const float* G;   int64_t g_ld;        /* [C, K] = gout^T xhat */
+    const float* gb;                       /* [C] */
+    float* dgamma;                         /* [K] */
+    float* dbeta;                          /* [K] */
+} macjd_lnparam_io;
+
+int macjd_layernorm_param_grad(const macjd_lnparam_io* io, void* hip_stream);
 
 /*
  * Fused chain of up to three dense layers, y = act_n(W_n ... act_1(W_1 x + b_1) ... + b_n), float32 with

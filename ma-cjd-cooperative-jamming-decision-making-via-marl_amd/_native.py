@@ -24,7 +24,7 @@ EXPORTS = [
     "macjd_env_reset", "macjd_env_step", "macjd_env_step_timed",
     "macjd_qhead_select", "macjd_gru_sequence", "macjd_mixer_tail_forward", "macjd_mixer_tail_backward",
     "macjd_mlp_forward", "macjd_mlp_forward_pair", "macjd_td_loss", "macjd_clip_adam_step", "macjd_gather_rows",
-    "macjd_linear_wgrad", "macjd_linear_wgrad_workspace_floats", "macjd_linear_wgrad_many", "macjd_qhead_input", "macjd_layernorm_forward", "macjd_gru_gates", "macjd_rowdot", "macjd_splitrelu_backward",
+    "macjd_linear_wgrad", "macjd_linear_wgrad_workspace_floats", "macjd_linear_wgrad_many", "macjd_qhead_input", "macjd_layernorm_forward", "macjd_layernorm_param_grad", "macjd_gru_gates", "macjd_rowdot", "macjd_splitrelu_backward",
 ]
 
 
@@ -144,6 +144,16 @@ class LayerNormIO(ctypes.Structure):
         ("eps", ctypes.c_float), ("reserved2", ctypes.c_float),
         ("x", ctypes.c_void_p), ("x_ld", ctypes.c_int64), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
         ("y", ctypes.c_void_p), ("y_ld", ctypes.c_int64), ("mean", ctypes.c_void_p), ("rstd", ctypes.c_void_p),
+        ("xhat", ctypes.c_void_p), ("xhat_ld", ctypes.c_int64),
+    ]
+
+
+class LnParamIO(ctypes.Structure):
+    """ctypes mirror of ``macjd_lnparam_io`` (include/macjd_nets.h)."""
+    _fields_ = [
+        ("C", ctypes.c_int32), ("K", ctypes.c_int32),
+        ("W", ctypes.c_void_p), ("w_ld", ctypes.c_int64), ("G", ctypes.c_void_p), ("g_ld", ctypes.c_int64),
+        ("gb", ctypes.c_void_p), ("dgamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p),
     ]
 
 
@@ -246,6 +256,8 @@ def load() -> ctypes.CDLL:
     lib.macjd_gru_gates.argtypes = [ctypes.POINTER(GruGatesIO), ctypes.c_void_p]
     lib.macjd_splitrelu_backward.restype = ctypes.c_int
     lib.macjd_splitrelu_backward.argtypes = [ctypes.POINTER(SplitReluBwdIO), ctypes.c_void_p]
+    lib.macjd_layernorm_param_grad.restype = ctypes.c_int
+    lib.macjd_layernorm_param_grad.argtypes = [ctypes.POINTER(LnParamIO), ctypes.c_void_p]
     lib.macjd_rowdot.restype = ctypes.c_int
     lib.macjd_rowdot.argtypes = [ctypes.POINTER(RowdotIO), ctypes.c_void_p]
     lib.macjd_mlp_forward_pair.restype = ctypes.c_int

@@ -231,8 +231,10 @@ class QMixer(nn.Module):
 
     def _hyper_networks(self, s):
         """(w1_raw [M,J*Em], b1_raw [M,Em], wf_raw [M,Em], v_raw [M,1]) from the normalised state."""
+        return self._hyper_tail(self._first_layer(s))           # [M, 2 Hh + 2 Em] -> the four heads
+
+    def _hyper_tail(self, out):
         Hh, Em = self.hyper_hidden_dim, self.embed_dim
-        out = self._first_layer(s)                              # [M, 2 Hh + 2 Em]
         # the three ReLUs are one launch over the first 2 Hh + Em columns, b1_raw is the remaining column block; the
         # backward of the whole split / ReLU / split is one launch too (ops.split_relu)
         h_w1, h_wf, h_v, b1_raw = ops.split_relu(out, [Hh, Hh, Em], Em)
@@ -246,7 +248,15 @@ class QMixer(nn.Module):
         It does not depend on the agents' Q-values, so a caller may evaluate it early / on another stream and hand
         the result to :meth:`forward` through ``hyper=``."""
         ln = self.state_norm
-        s = ops.layer_norm(states.reshape(-1, self.state_dim), ln.weight, ln.bias, ln.eps)
+        x = states.reshape(-1, self.state_dim)
+        if (self._merged_views is not None and x.is_cuda and torch.is_grad_enabled() and not x.requires_grad
+                and not self.bf16_hyper and ln.weight.requires_grad):
+            # training path on a HIP device: LayerNorm + merged first layer as one autograd node whose backward gets
+            # the LayerNorm's parameter gradients from the weight-gradient products (ops.norm_merged_linear)
+            w_cat, b_cat = self._merged_views
+            out = ops.norm_merged_linear(x, ln.weight, ln.bias, ln.eps, w_cat, b_cat, self.first_layer_params())
+            return self._hyper_tail(out)
+        s = ops.layer_norm(x, ln.weight, ln.bias, ln.eps)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(self.bf16_hyper and s.is_cuda)):
             raw = self._hyper_networks(s)
         if self.bf16_hyper and s.is_cuda:

@@ -737,6 +737,7 @@ __global__ void __launch_bounds__(256) layernorm_forward_kernel(const macjd_laye
             if (c < S) {
                 const float g = io.gamma ? io.gamma[c] : 1.0f, b = io.beta ? io.beta[c] : 0.0f;
                 y[c] = (v[i] - mean) * rstd * g + b;
+                if (io.xhat) io.xhat[m * io.xhat_ld + c] = (v[i] - mean) * rstd;
             }
         }
         if (lane == 0) {
@@ -954,6 +955,42 @@ extern "C" int macjd_splitrelu_backward(const macjd_splitrelu_bwd_io* io, void* 
     const int64_t blocks = (total + 255) / 256;
     hipLaunchKernelGGL(splitrelu_backward_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0,
                        (hipStream_t)hip_stream, *io, Cr);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
+    return MACJD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm gamma / beta gradients from the following Linear layer's weight-gradient quantities (see the header).
+namespace macjd {
+
+__global__ void __launch_bounds__(256) lnparam_kernel(const macjd_lnparam_io io) {
+    __shared__ float s_g[4], s_b[4];
+    const int k = blockIdx.x;
+    float sg = 0.0f, sb = 0.0f;
+    for (int c = threadIdx.x; c < io.C; c += blockDim.x) {
+        const float w = io.W[(int64_t)c * io.w_ld + k];
+        sg = fmaf(w, io.G[(int64_t)c * io.g_ld + k], sg);
+        sb = fmaf(w, io.gb[c], sb);
+    }
+    sg = wave_sum(sg);
+    sb = wave_sum(sb);
+    if ((threadIdx.x & 63) == 0) { s_g[threadIdx.x >> 6] = sg; s_b[threadIdx.x >> 6] = sb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        io.dgamma[k] = (s_g[0] + s_g[1]) + (s_g[2] + s_g[3]);
+        io.dbeta[k] = (s_b[0] + s_b[1]) + (s_b[2] + s_b[3]);
+    }
+}
+
+}  // namespace macjd
+
+extern "C" int macjd_layernorm_param_grad(const macjd_lnparam_io* io, void* hip_stream) {
+    using namespace macjd;
+    if (!io || io->C < 1 || io->K < 1 || !io->W || !io->G || !io->gb || !io->dgamma || !io->dbeta)
+        return set_nets_err(MACJD_EINVAL, "macjd_layernorm_param_grad: bad argument");
+    if (io->w_ld < io->K || io->g_ld < io->K) return set_nets_err(MACJD_EINVAL, "macjd_layernorm_param_grad: bad leading dimension");
+    hipLaunchKernelGGL(lnparam_kernel, dim3((unsigned)io->K), dim3(256), 0, (hipStream_t)hip_stream, *io);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
     return MACJD_OK;

@@ -539,6 +539,7 @@ def gather_rows(idx, srcs, dsts):
 # ---------------------------------------------------------------------------------------------
 # Linear with a split-K MFMA weight / bias gradient (csrc/macjd_wgrad.hip)
 _DEFERRED_WGRAD = None   # list of (WgradIO, keep-alive tensors) while a ``deferred_wgrad`` context is active
+_DEFERRED_POST = None    # callables run right after the grouped launches of that context
 
 
 class deferred_wgrad:
@@ -549,13 +550,23 @@ class deferred_wgrad:
     the flush: read them only after the context — and let autograd (or the caller) be their only owner until then."""
 
     def __enter__(self):
-        global _DEFERRED_WGRAD
+        global _DEFERRED_WGRAD, _DEFERRED_POST
         self._prev, _DEFERRED_WGRAD = _DEFERRED_WGRAD, []
+        self._prev_post, _DEFERRED_POST = _DEFERRED_POST, []
         return self
 
     def __exit__(self, *exc):
-        global _DEFERRED_WGRAD
+        global _DEFERRED_WGRAD, _DEFERRED_POST
         pending, _DEFERRED_WGRAD = _DEFERRED_WGRAD, self._prev
+        post, _DEFERRED_POST = _DEFERRED_POST, self._prev_post
+        self._flush(exc, pending)
+        if exc[0] is None:
+            for fn in post:      # launches that consume the flushed products (e.g. LayerNorm parameter gradients)
+                fn()
+        return False
+
+    @staticmethod
+    def _flush(exc, pending):
         if exc[0] is None and pending:
             lib = _native.load()
             dev = pending[0][1][0].device
@@ -565,7 +576,6 @@ class deferred_wgrad:
                 with torch.cuda.device(dev):
                     _native.check(lib.macjd_linear_wgrad_many(arr, len(part), _stream(part[0][1][0])),
                                   "macjd_linear_wgrad_many")
-        return False
 
 
 def linear_wgrad(gout, inp, want_bias=True):
@@ -635,6 +645,75 @@ def merged_linear(x, w_cat, b_cat, params):
     return _MergedLinear.apply(x, w_cat, b_cat, *params)
 
 
+def _layernorm_launch(x, weight, bias, eps, want_xhat):
+    lib = _native.load()
+    x = _f32c(x.detach())
+    M, S = x.shape
+    y = torch.empty((M, S), dtype=torch.float32, device=x.device)
+    mean = torch.empty((M, 1), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((M, 1), dtype=torch.float32, device=x.device)
+    xhat = torch.empty((M, S), dtype=torch.float32, device=x.device) if want_xhat else None
+    io = _native.LayerNormIO()
+    io.M, io.S, io.eps = M, S, float(eps)
+    io.x, io.x_ld, io.y, io.y_ld = x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0)
+    io.gamma = weight.data_ptr() if weight is not None else None
+    io.beta = bias.data_ptr() if bias is not None else None
+    io.mean, io.rstd = mean.data_ptr(), rstd.data_ptr()
+    if want_xhat:
+        io.xhat, io.xhat_ld = xhat.data_ptr(), xhat.stride(0)
+    with torch.cuda.device(x.device):
+        _native.check(lib.macjd_layernorm_forward(ctypes.byref(io), _stream(x)), "macjd_layernorm_forward")
+    return x, y, mean, rstd, xhat
+
+
+class _NormMergedLinear(torch.autograd.Function):
+    """out = LayerNorm(x; gamma, beta) W_cat^T + b_cat with W_cat / b_cat views of the flat parameter vector (see
+    _MergedLinear), for an input x that needs no gradient (the mixer's state): backward runs (inside
+    ``deferred_wgrad``: records) two split-K problems — gout^T s (the layers' weight / bias gradients) and G = gout^T xhat — and, after the
+    grouped launches, ONE small launch turns (W_cat, G, gb) into the LayerNorm's gamma / beta gradients
+    (macjd_layernorm_param_grad).  No [M, K] input-gradient GEMM, no LayerNorm-backward launches."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, w_cat, b_cat, *params):
+        _, s_, _, _, xhat = _layernorm_launch(x, gamma, beta, eps, want_xhat=True)
+        ctx.save_for_backward(s_, xhat, w_cat)
+        ctx.sizes = [p.shape[0] for p in params[:len(params) // 2]]
+        return F.linear(s_, w_cat, b_cat)
+
+    @staticmethod
+    def backward(ctx, gy):
+        s_, xhat, w_cat = ctx.saved_tensors
+        assert not ctx.needs_input_grad[0], "norm_merged_linear is for inputs that need no gradient"
+        gW, gb = linear_wgrad(gy, s_, want_bias=True)
+        G, _ = linear_wgrad(gy, xhat, want_bias=False)
+        K = w_cat.shape[1]
+        dgamma = torch.empty(K, dtype=torch.float32, device=gy.device)
+        dbeta = torch.empty(K, dtype=torch.float32, device=gy.device)
+        io = _native.LnParamIO()
+        io.C, io.K = w_cat.shape[0], K
+        io.W, io.w_ld, io.G, io.g_ld = w_cat.data_ptr(), w_cat.stride(0), G.data_ptr(), G.stride(0)
+        io.gb, io.dgamma, io.dbeta = gb.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr()
+        dev, stream = gy.device, _stream(gy)
+
+        def post(io=io, keep=(G, w_cat), dev=dev, stream=stream):   # gb / dgamma / dbeta live on as the parameters' .grad
+            with torch.cuda.device(dev):
+                _native.check(_native.load().macjd_layernorm_param_grad(ctypes.byref(io), stream), "macjd_layernorm_param_grad")
+
+        if _DEFERRED_WGRAD is not None:
+            _DEFERRED_POST.append(post)      # the products above are only recorded yet: run after the grouped launches
+        else:
+            post()
+        return (None, dgamma, dbeta, None, None, None) + tuple(gW.split(ctx.sizes, 0)) + tuple(gb.split(ctx.sizes, 0))
+
+
+def norm_merged_linear(x, gamma, beta, eps, w_cat, b_cat, params):
+    return _NormMergedLinear.apply(x, gamma, beta, eps, w_cat, b_cat, *params)
+
+
+def deferred_wgrad_active() -> bool:
+    return _DEFERRED_WGRAD is not None
+
+
 def qhead_input(h, idx, P, n_actions: int):
     """[h, onehot(idx), P] rows for the Q-head, [n, H + A + 1] float32 — one launch on a HIP device (the reference
     builds it with F.one_hot / torch.cat, core/networks.py:160-174).  Not differentiable (its inputs are data)."""
@@ -661,20 +740,7 @@ def qhead_input(h, idx, P, n_actions: int):
 class _LayerNormHip(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, eps):
-        lib = _native.load()
-        x = _f32c(x.detach())
-        M, S = x.shape
-        y = torch.empty((M, S), dtype=torch.float32, device=x.device)
-        mean = torch.empty((M, 1), dtype=torch.float32, device=x.device)
-        rstd = torch.empty((M, 1), dtype=torch.float32, device=x.device)
-        io = _native.LayerNormIO()
-        io.M, io.S, io.eps = M, S, float(eps)
-        io.x, io.x_ld, io.y, io.y_ld = x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0)
-        io.gamma = weight.data_ptr() if weight is not None else None
-        io.beta = bias.data_ptr() if bias is not None else None
-        io.mean, io.rstd = mean.data_ptr(), rstd.data_ptr()
-        with torch.cuda.device(x.device):
-            _native.check(lib.macjd_layernorm_forward(ctypes.byref(io), _stream(x)), "macjd_layernorm_forward")
+        x, y, mean, rstd, _ = _layernorm_launch(x, weight, bias, eps, want_xhat=False)
         ctx.save_for_backward(x, mean, rstd, weight, bias)
         return y
 

@@ -867,3 +867,37 @@ def test_mlp_forward_pair_equals_two_single_launches():
     for (xa, la), (xb, lb) in cases:
         ya, yb = ops.mlp_forward_pair(xa, la, xb, lb)
         assert torch.equal(ya, ops.mlp_forward(xa, la)) and torch.equal(yb, ops.mlp_forward(xb, lb))
+
+
+@pytest.mark.parametrize("deferred", [False, True])
+def test_norm_merged_linear_gradients_equal_autograd(deferred):
+    """LayerNorm -> Linear as one autograd node whose backward derives the LayerNorm gamma / beta gradients from the
+    Linear's weight-gradient products (dbeta = gb W, dgamma = sum_c W . (gout^T xhat)): same output and parameter
+    gradients as F.layer_norm + F.linear under stock autograd, immediately and inside ops.deferred_wgrad()."""
+    from macjd_amd import ops
+    g = torch.Generator().manual_seed(13)
+    M, K, sizes = 3232, 46, [128, 128, 64, 64]
+    C = sum(sizes)
+    x = (2.0 * torch.randn(M, K, generator=g) + 0.5).to(DEV)
+    gamma = (1.0 + 0.2 * torch.randn(K, generator=g)).to(DEV).requires_grad_(True)
+    beta = (0.1 * torch.randn(K, generator=g)).to(DEV).requires_grad_(True)
+    w_cat = (torch.randn(C, K, generator=g) / np.sqrt(K)).to(DEV)
+    b_cat = (0.1 * torch.randn(C, generator=g)).to(DEV)
+    ws = [w.clone().requires_grad_(True) for w in w_cat.split(sizes, 0)]
+    bs = [b.clone().requires_grad_(True) for b in b_cat.split(sizes, 0)]
+    up = torch.randn(M, C, generator=g).to(DEV)
+    out = ops.norm_merged_linear(x, gamma, beta, 1e-5, w_cat, b_cat, ws + bs)
+    if deferred:
+        with ops.deferred_wgrad():
+            out.backward(up)
+    else:
+        out.backward(up)
+    got = [gamma.grad, beta.grad] + [w.grad for w in ws] + [b.grad for b in bs]
+    g2, b2 = gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+    w2, bb2 = w_cat.clone().requires_grad_(True), b_cat.clone().requires_grad_(True)
+    ref_out = torch.nn.functional.linear(torch.nn.functional.layer_norm(x, (K,), g2, b2, 1e-5), w2, bb2)
+    ref_out.backward(up)
+    ref = [g2.grad, b2.grad] + list(w2.grad.split(sizes, 0)) + list(bb2.grad.split(sizes, 0))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref_out.detach().cpu().numpy(), atol=2e-5, rtol=1e-5)
+    for a, r in zip(got, ref):
+        np.testing.assert_allclose(a.cpu().numpy(), r.cpu().numpy(), atol=2e-5 * max(1.0, float(r.abs().max())), rtol=1e-4)
