@@ -230,16 +230,21 @@ class QMixLearner:
 
         # Two streams inside the (captured) update, balanced by hand from the kernel timeline
         # (scripts/timeline_update.py):
-        #   side stream   (no grad) fc1 / GRU-input GEMMs of both controllers -> the fused scan (~85 us latency chain)
-        #                 -> Q-head base GEMMs
-        #   this stream   (no grad) the frozen actor chains -> (autograd) Q-head on the STORED hidden states + eval
-        #                 mixer -> (no grad) the target mixer's hyper-networks (they read only the state)
+        #   side stream   (no grad) fc1 / GRU-input GEMMs of both controllers -> the fused scan (~65 us latency chain)
+        #                 -> Q-head base GEMMs -> the frozen actor chains of both controllers (one launch)
+        #   this stream   (autograd) Q-head on the STORED hidden states + eval mixer -> (no grad) the target mixer's
+        #                 hyper-networks (they read only the state)
         #   ONE join, then on this stream the two Double-DQN Q-head launches, the target mixer tail and the loss.
         # Autograd only ever sees this stream.  The split took the step from 0.565 to 0.490 ms when it was introduced.
-        # Variants measured equal within run-to-run noise on one box (0.465-0.489 ms, 3 interleaved runs each): the
-        # Q-head / tail launches on the side stream behind two events, and a third stream for the actor /
-        # hyper-network work — so the simplest layout stays.  Forks taken from a forked stream crash
-        # hipStreamEndCapture (ROCm 7.2): every fork hangs off the capture's origin stream.
+        # MACJD_UPDATE_LAYOUT picks where the two movable no-grad pieces run (10 interleaved bench runs each on one
+        # box, median ms / step):  0 = actor chains + target hyper-networks on this stream      0.3855
+        #                          1 = target hyper-networks behind the scan chain instead      0.3742
+        #                          2 = actor chains behind the scan chain instead (default)     0.3693
+        # (timeline before: side stream done at ~120 us, this stream at ~220 us; the branch a replayed graph starts
+        # second begins 30 - 50 us late whatever it holds).  Variants measured equal within noise earlier: the Q-head /
+        # tail launches on the side stream behind two events, a third stream for the actor / hyper-network work.
+        # Forks taken from a forked stream crash hipStreamEndCapture (ROCm 7.2): every fork hangs off the capture's
+        # origin stream.
         def scan_chain():
             gis = [m.agent.gru_input_transform(rows).view(B, T1, J, 3 * H) for m in macs]      # networks.py:100
             h_alls = ops.gru_sequence_multi(gis, [m.agent.rnn.weight_hh for m in macs],
@@ -269,17 +274,26 @@ class QMixLearner:
             if getattr(self, "_target_stream", None) is None:
                 self._target_stream = torch.cuda.Stream(device=dev)
             ts = self._target_stream
+            layout = int(os.environ.get("MACJD_UPDATE_LAYOUT", "2"))   # A/B switch, see the table above
             ts.wait_stream(origin)                                                              # fork
+            params = hyper = None
             with torch.cuda.stream(ts), torch.no_grad():
                 bases = scan_chain()
-            with torch.no_grad():
-                params = actor_chains()
+                if layout == 1:
+                    hyper = self.target_qmix_net.hyper_outputs(st["state"])
+                if layout == 2:
+                    params = actor_chains()
+            if params is None:
+                with torch.no_grad():
+                    params = actor_chains()
             eval_q_tot = eval_forward()
             with torch.no_grad():
-                hyper = self.target_qmix_net.hyper_outputs(st["state"])
+                if hyper is None:
+                    hyper = self.target_qmix_net.hyper_outputs(st["state"])
                 origin.wait_stream(ts)                                                          # join
-                for t_ in bases:
-                    t_.record_stream(origin)
+                for t_ in list(bases) + ([*hyper] if layout == 1 else []) + ([*params] if layout == 2 else []):
+                    if torch.is_tensor(t_):
+                        t_.record_stream(origin)
                 target_q_tot = target_q_tot_of(bases, params, hyper)
         else:
             with torch.no_grad():

@@ -7,9 +7,9 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")) for r in rows))
-# the timed region ends with the last gather_rows_kernel .. adam_bump pattern: take the last complete update
+# the timed region ends with the last gather_rows_kernel .. adam_update_kernel pattern: take the last complete update
 idx = [i for i, e in enumerate(ev) if "gather_rows_kernel" in e[2]]
-bumps = [i for i, e in enumerate(ev) if "adam_bump_step_kernel" in e[2]]
+bumps = [i for i, e in enumerate(ev) if "adam_update_kernel" in e[2]]
 lo = idx[-2] if len(idx) >= 2 and idx[-1] > bumps[-1] else idx[-1]
 hi = [b for b in bumps if b > lo][0]
 step = ev[lo:hi + 1]
@@ -32,3 +32,24 @@ print(f" no kernel running: {idle / 1e3:.1f} us in {len(gaps)} gaps; largest: " 
 print(" timeline (start us, dur us, queue, kernel):")
 for s, e, n, q in step:
     print(f"  {(s - t0) / 1e3:7.1f} {(e - s) / 1e3:6.1f}  q{q}  {n[:70]}")
+
+# median over ALL complete updates in the trace of the idle time in front of each kernel on its own queue
+# (one update's timeline is a single sample; a gap that shows in the median is real)
+import statistics
+starts = [i for i in idx if any(b > i for b in bumps)]
+per_pos = {}
+for lo_i in starts:
+    hi_i = [b for b in bumps if b > lo_i][0]
+    upd = ev[lo_i:hi_i + 1]
+    if len(upd) != len(step):
+        continue
+    last_end = {}
+    for pos, (s, e, n, q) in enumerate(upd):
+        if q in last_end:
+            per_pos.setdefault(pos, []).append((s - last_end[q]) / 1e3)
+        last_end[q] = e
+print(f" median idle time before each kernel on its queue over {len(per_pos.get(1, []))} updates (only > 3 us shown):")
+for pos, gaps_ in sorted(per_pos.items()):
+    med = statistics.median(gaps_)
+    if med > 3.0:
+        print(f"  #{pos:2d} {med:6.1f} us before {step[pos][2][:60]}")
