@@ -301,6 +301,7 @@ typedef struct macjd_splitrelu_bwd_io {
     const float* g_pass; int64_t gp_ld;      /* [M, Cp] */
     const float* act;   int64_t act_ld;      /* [M, Cr] ReLU output saved by the forward */
     float* gout;        int64_t gout_ld;     /* [M, Cr + Cp] */
+    const float* outer_w[4];                 /* NULL, or [width[k]]: block k's gradient is g[k][m] * outer_w[k][c] */
 } macjd_splitrelu_bwd_io;
 
 int macjd_splitrelu_backward(const macjd_splitrelu_bwd_io* io, void* hip_stream);

@@ -134,6 +134,7 @@ class SplitReluBwdIO(ctypes.Structure):
         ("g_ld", ctypes.c_int64 * 4),
         ("g_pass", ctypes.c_void_p), ("gp_ld", ctypes.c_int64),
         ("act", ctypes.c_void_p), ("act_ld", ctypes.c_int64), ("gout", ctypes.c_void_p), ("gout_ld", ctypes.c_int64),
+        ("ow0", ctypes.c_void_p), ("ow1", ctypes.c_void_p), ("ow2", ctypes.c_void_p), ("ow3", ctypes.c_void_p),
     ]
 
 

@@ -150,7 +150,7 @@ class RNNAgent(nn.Module):
         # cat([h, onehot(a), P]) -> Linear -> ReLU -> Linear, exactly the reference's formulation (networks.py:171-176);
         # the one-hot is a compare + cast (any integer dtype), the Linears use the split-K weight gradient on a HIP device
         q_head_input = ops.qhead_input(hidden_state, idx, continuous_param, self.n_actions)   # [h, onehot(a), P]
-        return ops.linear(ops.linear_relu(q_head_input, l1.weight, l1.bias), l2.weight, l2.bias)
+        return ops.linear_relu_dot(q_head_input, l1.weight, l1.bias, l2.weight, l2.bias)
 
     def q_values_all_actions(self, hidden_state, continuous_params_all):
         """Q(h, a, P[:, a]) for all a at once, [N, A].  Inference path (no autograd): replaces the
@@ -236,11 +236,12 @@ class QMixer(nn.Module):
     def _hyper_tail(self, out):
         Hh, Em = self.hyper_hidden_dim, self.embed_dim
         # the three ReLUs are one launch over the first 2 Hh + Em columns, b1_raw is the remaining column block; the
-        # backward of the whole split / ReLU / split is one launch too (ops.split_relu)
-        h_w1, h_wf, h_v, b1_raw = ops.split_relu(out, [Hh, Hh, Em], Em)
+        # backward of the whole split / ReLU / split is one launch too
+        # (ops.split_relu); the V head's one-output second layer rides in the same node (its backward is an outer product
+        # folded into that launch)
+        h_w1, h_wf, v_raw, b1_raw = ops.split_relu(out, [Hh, Hh, Em], Em, dot=(2, self.V[2].weight, self.V[2].bias))
         w1_raw = ops.linear(h_w1, self.hyper_w_1[2].weight, self.hyper_w_1[2].bias)
         wf_raw = ops.linear(h_wf, self.hyper_w_final[2].weight, self.hyper_w_final[2].bias)
-        v_raw = ops.linear(h_v, self.V[2].weight, self.V[2].bias)
         return w1_raw, b1_raw, wf_raw, v_raw
 
     def hyper_outputs(self, states):

@@ -929,7 +929,8 @@ __global__ void __launch_bounds__(256) splitrelu_backward_kernel(const macjd_spl
                 if (q + 1 < io.n_blocks && c >= start + io.width[k]) { start += io.width[k]; ++k; }
             const float* gk = (k == 0) ? io.g[0] : (k == 1) ? io.g[1] : (k == 2) ? io.g[2] : io.g[3];
             const int64_t ld = (k == 0) ? io.g_ld[0] : (k == 1) ? io.g_ld[1] : (k == 2) ? io.g_ld[2] : io.g_ld[3];
-            const float gv = gk ? gk[m * ld + (c - start)] : 0.0f;
+            const float* ow = (k == 0) ? io.outer_w[0] : (k == 1) ? io.outer_w[1] : (k == 2) ? io.outer_w[2] : io.outer_w[3];
+            const float gv = !gk ? 0.0f : ow ? gk[m * ld] * ow[c - start] : gk[m * ld + (c - start)];
             v = (io.act[m * io.act_ld + c] > 0.0f) ? gv : 0.0f;
         }
         io.gout[m * io.gout_ld + c] = v;
@@ -945,7 +946,8 @@ extern "C" int macjd_splitrelu_backward(const macjd_splitrelu_bwd_io* io, void* 
     int Cr = 0;
     for (int k = 0; k < io->n_blocks; ++k) {
         if (io->width[k] < 1) return set_nets_err(MACJD_EINVAL, "macjd_splitrelu_backward: bad block width");
-        if (io->g[k] && io->g_ld[k] < io->width[k]) return set_nets_err(MACJD_EINVAL, "macjd_splitrelu_backward: bad g_ld");
+        if (io->g[k] && io->g_ld[k] < (io->outer_w[k] ? 1 : io->width[k]))
+            return set_nets_err(MACJD_EINVAL, "macjd_splitrelu_backward: bad g_ld");
         Cr += io->width[k];
     }
     if (io->act_ld < Cr || io->gout_ld < Cr + io->Cp || (io->g_pass && io->gp_ld < io->Cp))

@@ -9,6 +9,7 @@ environment step itself has no CPU branch at all.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -761,61 +762,100 @@ def layer_norm(x, weight, bias, eps: float = 1e-5):
     return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
 
 
+# A/B switch: the one-output Linear layers (Q-head second layer, mixer V head) ride inside the node that produces
+# their input, so their backward outer product is folded into that node's one backward launch
+FOLD_ROWDOT = os.environ.get("MACJD_FOLD_ROWDOT", "1") != "0"
+
+
+def _splitrelu_backward_launch(act, widths, Cp, grads, g_pass, outer):
+    """gout [M, sum(widths) + Cp] of macjd_splitrelu_backward; ``outer[k]`` (or None) is the one-row weight of a
+    one-output Linear that consumed block k, ``grads[k]`` then being that layer's [M, 1] output gradient."""
+    lib = _native.load()
+    M = act.shape[0]
+    gout = torch.empty((M, sum(widths) + Cp), dtype=torch.float32, device=act.device)
+    io = _native.SplitReluBwdIO()
+    io.M, io.n_blocks, io.Cp = M, len(widths), Cp
+    keep = []
+    for k, wk in enumerate(widths):
+        io.width[k] = wk
+        g = grads[k]
+        if g is None:
+            continue
+        g = _f32c(g)
+        keep.append(g)
+        setattr(io, f"g{k}", g.data_ptr())
+        io.g_ld[k] = g.stride(0)
+        if outer[k] is not None:
+            w = outer[k].detach().reshape(-1).float().contiguous()
+            keep.append(w)
+            setattr(io, f"ow{k}", w.data_ptr())
+    if Cp and g_pass is not None:
+        gp = _f32c(g_pass)
+        keep.append(gp)
+        io.g_pass, io.gp_ld = gp.data_ptr(), gp.stride(0)
+    io.act, io.act_ld, io.gout, io.gout_ld = act.data_ptr(), act.stride(0), gout.data_ptr(), gout.stride(0)
+    with torch.cuda.device(act.device):
+        _native.check(lib.macjd_splitrelu_backward(ctypes.byref(io), _stream(act)), "macjd_splitrelu_backward")
+    return gout
+
+
 class _SplitRelu(torch.autograd.Function):
     """(ReLU(x[:, :w0]), ReLU(x[:, w0:w0+w1]), ..., x[:, Cr:]) for a [M, Cr + Cp] matrix: the ReLU blocks are column
     views of ONE activation buffer (one forward launch, as before); the backward writes the masked block gradients
     and the pass-through gradient into the [M, Cr + Cp] result with ONE launch (autograd: cat + threshold_backward +
-    cat)."""
+    cat).  With ``dot_k >= 0`` block dot_k is not returned itself but fed through a one-output Linear (weight
+    [1, w_k], bias [1]; the mixer's V head): forward = the row-dot launch, backward = the outer product folded into the
+    same backward launch, the Linear's weight gradient through ``linear_wgrad`` like every other layer."""
 
     @staticmethod
-    def forward(ctx, x, widths, Cp):
+    def forward(ctx, x, widths, Cp, dot_k, dot_w, dot_b):
         Cr = sum(widths)
         act = torch.relu(x[:, :Cr])                     # contiguous [M, Cr]
-        ctx.save_for_backward(act)
-        ctx.widths, ctx.Cp, ctx.shape = list(widths), int(Cp), tuple(x.shape)
+        ctx.widths, ctx.Cp, ctx.dot_k = list(widths), int(Cp), int(dot_k)
         outs = list(act.split(widths, dim=1))
+        if dot_k >= 0:
+            ctx.save_for_backward(act, dot_w)
+            ctx.has_bias = dot_b is not None
+            outs[dot_k] = _rowdot_launch(outs[dot_k], dot_w, dot_b)
+        else:
+            ctx.save_for_backward(act)
         if Cp:
             outs.append(x[:, Cr:])
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
-        (act,) = ctx.saved_tensors
-        lib = _native.load()
-        M, W = ctx.shape
-        gout = torch.empty((M, W), dtype=torch.float32, device=act.device)
-        io = _native.SplitReluBwdIO()
-        io.M, io.n_blocks, io.Cp = M, len(ctx.widths), ctx.Cp
-        keep = []
-        for k, wk in enumerate(ctx.widths):
-            io.width[k] = wk
-            g = grads[k]
-            if g is not None:
-                g = _f32c(g)
-                keep.append(g)
-                setattr(io, f"g{k}", g.data_ptr())
-                io.g_ld[k] = g.stride(0)
-        if ctx.Cp and grads[len(ctx.widths)] is not None:
-            gp = _f32c(grads[len(ctx.widths)])
-            keep.append(gp)
-            io.g_pass, io.gp_ld = gp.data_ptr(), gp.stride(0)
-        io.act, io.act_ld, io.gout, io.gout_ld = act.data_ptr(), act.stride(0), gout.data_ptr(), gout.stride(0)
-        with torch.cuda.device(act.device):
-            _native.check(lib.macjd_splitrelu_backward(ctypes.byref(io), _stream(act)), "macjd_splitrelu_backward")
-        return gout, None, None
+        act = ctx.saved_tensors[0]
+        nb, k = len(ctx.widths), ctx.dot_k
+        outer = [None] * nb
+        gW = gb = None
+        if k >= 0:
+            dot_w = ctx.saved_tensors[1]
+            outer[k] = dot_w
+            if grads[k] is not None and (ctx.needs_input_grad[4] or (ctx.has_bias and ctx.needs_input_grad[5])):
+                h = act.split(ctx.widths, dim=1)[k]
+                gW, gb = linear_wgrad(grads[k].reshape(-1, 1), h, want_bias=ctx.has_bias)
+        gout = _splitrelu_backward_launch(act, ctx.widths, ctx.Cp, grads, grads[nb] if ctx.Cp else None, outer)
+        return gout, None, None, None, gW, (gb if k >= 0 and ctx.has_bias else None)
 
 
-def split_relu(x, relu_widths, pass_width: int):
+def split_relu(x, relu_widths, pass_width: int, dot=None):
     """Column blocks of a 2-D tensor: ReLU on the first ``sum(relu_widths)`` columns (returned as blocks of those
-    widths), the last ``pass_width`` columns unchanged.  HIP device + autograd: fused backward (see _SplitRelu)."""
+    widths), the last ``pass_width`` columns unchanged.  ``dot = (k, weight [1, w_k], bias)`` replaces block k in the
+    result by ``F.linear(block_k, weight, bias)``.  HIP device + autograd: fused backward (see _SplitRelu)."""
     widths = [int(w) for w in relu_widths]
     if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and torch.is_grad_enabled() and x.requires_grad \
             and 1 <= len(widths) <= 4 and not torch.is_autocast_enabled():
-        return _SplitRelu.apply(x, widths, int(pass_width))
-    Cr = sum(widths)
-    outs = list(torch.relu(x[:, :Cr]).split(widths, dim=1))
-    if pass_width:
-        outs.append(x[:, Cr:])
+        if dot is not None and FOLD_ROWDOT and _rowdot_ok(x[:, :widths[dot[0]]], dot[1]):
+            return _SplitRelu.apply(x, widths, int(pass_width), int(dot[0]), dot[1], dot[2])
+        outs = list(_SplitRelu.apply(x, widths, int(pass_width), -1, None, None))
+    else:
+        Cr = sum(widths)
+        outs = list(torch.relu(x[:, :Cr]).split(widths, dim=1))
+        if pass_width:
+            outs.append(x[:, Cr:])
+    if dot is not None:
+        outs[dot[0]] = linear(outs[dot[0]], dot[1], dot[2])
     return tuple(outs)
 
 
@@ -890,6 +930,38 @@ def linear_relu(x, weight, bias):
             return F.relu(linear(x, weight, bias))
         return torch._addmm_activation(bias, x, weight.t(), use_gelu=False)
     return F.relu(linear(x, weight, bias))
+
+
+class _LinearReluRowDot(torch.autograd.Function):
+    """q = relu(x W1^T + b1) w2^T + b2 with a one-row w2 (the MP-DQN Q-head, reference core/networks.py:75-79) as ONE
+    autograd node: forward = GEMM with the bias + ReLU epilogue, row-dot launch; backward = ONE launch for
+    gq w2 masked by the ReLU (autograd: broadcast product + threshold_backward), then both layers' weight gradients
+    through ``linear_wgrad``."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        y = torch._addmm_activation(b1, x, w1.t(), use_gelu=False)
+        ctx.save_for_backward(x, w1, y, w2)
+        ctx.has_b2 = b2 is not None
+        return _rowdot_launch(y, w2, b2)
+
+    @staticmethod
+    def backward(ctx, gq):
+        x, w1, y, w2 = ctx.saved_tensors
+        g = _splitrelu_backward_launch(y, [y.shape[1]], 0, [gq], None, [w2])
+        gx = g.matmul(w1) if ctx.needs_input_grad[0] else None
+        gW1, gb1 = linear_wgrad(g, x, want_bias=True)
+        gW2, gb2 = linear_wgrad(gq.reshape(-1, 1), y, want_bias=ctx.has_b2)
+        return gx, gW1, gb1, gW2, (gb2 if ctx.has_b2 else None)
+
+
+def linear_relu_dot(x, w1, b1, w2, b2):
+    """F.linear(relu(F.linear(x, w1, b1)), w2, b2) for a one-output second layer; one autograd node on a HIP device."""
+    if (FOLD_ROWDOT and _fused_relu_ok(x, w1, b1) and torch.is_grad_enabled() and (w1.requires_grad or w2.requires_grad or x.requires_grad)
+            and x.dim() == 2 and x.shape[0] >= 1024 and w1.shape[0] * w1.shape[1] <= 384 * 256 and x.stride(-1) == 1
+            and w2.shape[0] == 1 and w1.shape[0] % 4 == 0 and 4 <= w1.shape[0] <= 1024 and not torch.is_autocast_enabled()):
+        return _LinearReluRowDot.apply(x, w1, b1, w2, b2)
+    return linear(linear_relu(x, w1, b1), w2, b2)
 
 
 def linear(x, weight, bias=None):

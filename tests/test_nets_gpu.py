@@ -795,6 +795,81 @@ def test_split_relu_fused_backward_equals_autograd():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("deferred", [False, True])
+def test_split_relu_with_folded_one_output_layer_equals_autograd(deferred):
+    """ops.split_relu(..., dot=(k, w, b)): block k goes through a one-output Linear inside the node (row-dot forward,
+    outer product folded into the one backward launch).  Values and every gradient == the unfused ops (bitwise)."""
+    from macjd_amd import ops
+    g = torch.Generator().manual_seed(33)
+    M, widths, Cp = 3232, [128, 128, 32], 32
+    x = torch.randn(M, sum(widths) + Cp, generator=g).to(DEV).requires_grad_(True)
+    w = torch.randn(1, 32, generator=g).to(DEV).requires_grad_(True)
+    b = torch.randn(1, generator=g).to(DEV).requires_grad_(True)
+    ups = [torch.randn(M, c, generator=g).to(DEV) for c in (128, 128, 1, Cp)]
+
+    def run(fused):
+        for t in (x, w, b):
+            t.grad = None
+        if fused:
+            outs = ops.split_relu(x, widths, Cp, dot=(2, w, b))
+        else:
+            outs = list(ops.split_relu(x, widths, Cp))
+            outs[2] = ops.linear(outs[2], w, b)
+        loss = sum((o * u).sum() for o, u in zip(outs, ups))
+        if deferred and fused:
+            with ops.deferred_wgrad():
+                loss.backward()
+        else:
+            loss.backward()
+        return [o.detach().clone() for o in outs], [t.grad.clone() for t in (x, w, b)]
+
+    o_ref, g_ref = run(False)
+    o_got, g_got = run(True)
+    assert o_got[2].shape == (M, 1)
+    for a, c in zip(o_ref + g_ref, o_got + g_got):
+        assert torch.equal(a, c)
+    # against stock torch ops: same values up to the GEMM-vs-row-dot summation order of the one-output layer
+    x2, w2, b2 = (t.detach().clone().requires_grad_(True) for t in (x, w, b))
+    r = list(torch.relu(x2[:, :sum(widths)]).split(widths, dim=1)) + [x2[:, sum(widths):]]
+    r[2] = torch.nn.functional.linear(r[2], w2, b2)
+    sum((o * u).sum() for o, u in zip(r, ups)).backward()
+    assert torch.equal(g_got[0], x2.grad)
+    torch.testing.assert_close(g_got[1], w2.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(o_got[2], r[2].detach(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("deferred", [False, True])
+def test_linear_relu_dot_node_equals_unfused_layers(deferred):
+    """ops.linear_relu_dot (the Q-head's two layers as one autograd node) == ops.linear(ops.linear_relu(...)) bitwise:
+    output, input gradient and all four parameter gradients."""
+    from macjd_amd import ops
+    g = torch.Generator().manual_seed(34)
+    N, K, Hd = 9696, 74, 64
+    x = torch.randn(N, K, generator=g).to(DEV).requires_grad_(True)
+    w1 = (torch.randn(Hd, K, generator=g) * 0.2).to(DEV).requires_grad_(True)
+    b1 = torch.randn(Hd, generator=g).to(DEV).requires_grad_(True)
+    w2 = torch.randn(1, Hd, generator=g).to(DEV).requires_grad_(True)
+    b2 = torch.randn(1, generator=g).to(DEV).requires_grad_(True)
+    up = torch.randn(N, 1, generator=g).to(DEV)
+    ps = (x, w1, b1, w2, b2)
+
+    def run(fused):
+        for t in ps:
+            t.grad = None
+        q = ops.linear_relu_dot(x, w1, b1, w2, b2) if fused else ops.linear(ops.linear_relu(x, w1, b1), w2, b2)
+        if deferred and fused:
+            with ops.deferred_wgrad():
+                (q * up).sum().backward()
+        else:
+            (q * up).sum().backward()
+        return [q.detach().clone()] + [t.grad.clone() for t in ps]
+
+    ref, got = run(False), run(True)
+    assert type(ops.linear_relu_dot(x, w1, b1, w2, b2).grad_fn).__name__.startswith("_LinearReluRowDot")
+    for a, c in zip(ref, got):
+        assert torch.equal(a, c)
+
+
 def test_deferred_grouped_weight_gradients_equal_immediate():
     """Inside ops.deferred_wgrad() the split-K weight gradients of several layers run as ONE partial-products launch +
     ONE reduce launch at the end: bitwise the same results as the per-layer launches, for more problems than one
