@@ -354,7 +354,8 @@ class QMixLearner:
 
     # ------------------------------------------------------------------ HIP-graph path
     def enable_graphs(self, buffer, batch_size, warmup_iters=3):
-        """Capture the update as two HIP graphs around the (eager) gradient all-reduce:
+        """Capture the update as two HIP graphs around the (eager) gradient all-reduce (ONE graph holding both halves
+        when there is a single process, i.e. nothing to all-reduce):
           graph A  gather the sampled episodes from the device replay (static index tensor) + both
                    unrolls + mixers + loss + backward                      (~300 launches -> 1 graph launch)
           graph B  gradient clipping + Adam + the four logged scalars
@@ -411,11 +412,16 @@ class QMixLearner:
                         old = snap_o.get(id(p), {}).get(k)
                         v.copy_(old) if old is not None else v.zero_()
         self._graph_a, self._graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        # a single process has no all-reduce between the two halves: one graph, one launch per update
+        self._g_single = self._world_size() <= 1 and os.environ.get("MACJD_SINGLE_UPDATE_GRAPH", "1") != "0"
         # thread_local: other threads (RCCL's watchdog polls events) may touch the runtime during capture
         with torch.cuda.graph(self._graph_a, capture_error_mode="thread_local"):
             self._g_out_a = body_a()
-        with torch.cuda.graph(self._graph_b, pool=self._graph_a.pool(), capture_error_mode="thread_local"):
-            self._g_out_b = self._clip_and_step()
+            if self._g_single:
+                self._g_out_b = self._clip_and_step()
+        if not self._g_single:
+            with torch.cuda.graph(self._graph_b, pool=self._graph_a.pool(), capture_error_mode="thread_local"):
+                self._g_out_b = self._clip_and_step()
         self._graphs_ready = True
 
     def train_from_buffer(self, indices=None, sync_stats=True):
@@ -431,8 +437,9 @@ class QMixLearner:
         self.train_step += 1
         self._g_idx.copy_(torch.from_numpy(indices))
         self._graph_a.replay()
-        self._allreduce_grads()
-        self._graph_b.replay()
+        if not self._g_single:
+            self._allreduce_grads()
+            self._graph_b.replay()
         self._after_step()
         loss, ev, tg = self._g_out_a
         return self._pack_stats(loss, self._g_out_b, ev, tg, sync_stats)

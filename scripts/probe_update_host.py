@@ -41,7 +41,10 @@ print(f"per update: host enqueue {1e6 * (t1 - t0) / N:.1f} us, wall incl. final 
 import numpy as np
 ta = tb = 0.0
 for _ in range(N):
-    a = time.perf_counter(); learner._graph_a.replay(); b = time.perf_counter(); learner._graph_b.replay(); c = time.perf_counter()
+    a = time.perf_counter(); learner._graph_a.replay(); b = time.perf_counter()
+    if not learner._g_single:   # one process: both halves are in graph A (set MACJD_SINGLE_UPDATE_GRAPH=0 for two)
+        learner._graph_b.replay()
+    c = time.perf_counter()
     ta += b - a; tb += c - b
 torch.cuda.synchronize()
 print(f"host time of graph A replay {1e6 * ta / N:.1f} us, graph B replay {1e6 * tb / N:.1f} us")

@@ -331,9 +331,11 @@ def test_gru_sequence_kernel(H, B, T, J):
     assert torch.equal(single, got[0])
 
 
-@pytest.mark.parametrize("T,N,B,steps", [(12, 40, 8, 7), (100, 48, 32, 4)])
-def test_graphed_train_equals_eager_train(T, N, B, steps):
-    """HIP-graph replay of the learner step == the eager step: same sampled episodes -> same losses and
+@pytest.mark.parametrize("T,N,B,steps,single", [(12, 40, 8, 7, "1"), (100, 48, 32, 4, "1"), (100, 48, 32, 4, "0")])
+def test_graphed_train_equals_eager_train(T, N, B, steps, single, monkeypatch):
+    """HIP-graph replay (one graph per update for a single process; two graphs around the gradient all-reduce otherwise,
+    forced here with MACJD_SINGLE_UPDATE_GRAPH=0 so that the layout every rank of a multi-GPU job runs is covered too)
+    of the learner step == the eager step.  HIP-graph replay of the learner step == the eager step: same sampled episodes -> same losses and
     the same weights after several updates incl. a target sync.  The second size is the benchmark's (32 episodes x
     101 steps x 3 agents = 9696 rows): only there do the split-K / grouped weight gradients, the row-dot and the
     fused-ReLU paths engage (they need >= 1024 rows), and every step samples different episodes, so a gradient that
@@ -342,6 +344,7 @@ def test_graphed_train_equals_eager_train(T, N, B, steps):
     from macjd_amd.core.qmix import QMixLearner
     from macjd_amd.utils.replay_buffer import EpisodeReplayBuffer
     from tests_golden_helpers import synthetic_batch
+    monkeypatch.setenv("MACJD_SINGLE_UPDATE_GRAPH", single)
     g, d = load("3j4r_h64")
     def build():
         args = _gpu_args(d, episode_limit=T, buffer_size=N, batch_size=B, target_update_interval=3)
