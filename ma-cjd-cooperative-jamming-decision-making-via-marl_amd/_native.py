@@ -11,7 +11,8 @@ from typing import Optional
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libmacjd_hip.so"
-LIB_PATH = os.path.join(_PKG_DIR, LIB_NAME)
+# MACJD_LIB points at another build of the same sources (kernel A/B runs); the default is the in-tree library
+LIB_PATH = os.environ.get("MACJD_LIB") or os.path.join(_PKG_DIR, LIB_NAME)
 
 ABI_VERSION = 2
 STEP_ARITH_F64 = 1

@@ -23,7 +23,10 @@
 namespace macjd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int WG_BM = 64, WG_BN = 64, WG_KC = 128, WG_PITCH = 80;
+#ifndef MACJD_WG_KC
+#define MACJD_WG_KC 128   // rows of the reduction per workgroup (tuning knob: -DMACJD_WG_KC=64 halves LDS per workgroup)
+#endif
+constexpr int WG_BM = 64, WG_BN = 64, WG_KC = MACJD_WG_KC, WG_PITCH = 80;
 
 __host__ __device__ inline int64_t wg_pad(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
