@@ -69,6 +69,7 @@ class QMixLearner:
         self.last_target_update_step = 0
         self.train_step = 0
         self._flat_grad = None   # flat gradient vector (all-reduce buffer / input of the fused optimiser step)
+        self.grad_pack_launches = 0   # updates whose gradients had to be packed into the flat vector by a copy
         self._flat_param = None
         if self.device.type == "cuda":
             self._flatten_trainable()
@@ -109,12 +110,23 @@ class QMixLearner:
             self.optimizer.state[p] = {"step": self._adam_step, "exp_avg": self._flat_exp_avg[off:off + n].view_as(p),
                                        "exp_avg_sq": self._flat_exp_avg_sq[off:off + n].view_as(p)}
             off += n
+        # gradients: ONE flat vector too (the all-reduce buffer); the weight-gradient kernels write their results
+        # straight into its slices (ops.deferred_wgrad(grad_dst=...)), so nothing packs the gradients afterwards
+        self._flat_grad = torch.zeros_like(flat)
+        self._grad_dst, off = {}, 0
+        for p in tr:
+            n = p.numel()
+            self._grad_dst[ops.grad_key(p)] = self._flat_grad[off:off + n].view_as(p)
+            off += n
         # merged first layer of the eval mixer = the leading block of the flat vector; the target mixer (inference
         # only) keeps a cached concatenation that its load_state_dict refreshes in place
         mx = self.eval_qmix_net
         first = mx.first_layer_params()
         rows, S = sum(p.shape[0] for p in first[:4]), first[0].shape[1]
         mx._merged_views = (flat[:rows * S].view(rows, S), flat[rows * S:rows * S + rows])
+        # the merged views alias the first parameter of their block: same address, different size -> different key
+        self._grad_dst[ops.grad_key(mx._merged_views[0])] = self._flat_grad[:rows * S].view(rows, S)
+        self._grad_dst[ops.grad_key(mx._merged_views[1])] = self._flat_grad[rows * S:rows * S + rows]
         self.target_qmix_net.enable_first_layer_cache()
 
     def load_optimizer_state(self, state_dict):
@@ -141,13 +153,23 @@ class QMixLearner:
         return torch.cat([p.grad.reshape(-1) for p in self._trainable()])
 
     def _flatten_grads(self):
-        """world_size > 1 only: ONE cat packs the freshly computed gradients into the flat all-reduce buffer and
-        every ``.grad`` becomes a view of it (clip + Adam then read the reduced values).  With a single rank the
-        gradients stay where autograd put them — no packing, no accumulate-into-buffer adds, no memset."""
+        """Every ``.grad`` becomes a view of ONE flat vector (the all-reduce buffer; clip + Adam read it).  On the
+        graphed HIP path the weight-gradient kernels have already written into it (``_grad_dst``) and this is a
+        host-side check only; gradients that stock autograd produced (small batches, CPU) are packed with one cat."""
         tr = self._trainable()
         if self._flat_grad is None:
             self._flat_grad = torch.empty(sum(p.numel() for p in tr), dtype=tr[0].dtype, device=tr[0].device)
-        torch.cat([p.grad.reshape(-1) for p in tr], out=self._flat_grad)
+        base, esz, off, in_place = self._flat_grad.data_ptr(), self._flat_grad.element_size(), 0, 0
+        for p in tr:
+            in_place += int(p.grad is not None and p.grad.data_ptr() == base + off * esz and p.grad.is_contiguous())
+            off += p.numel()
+        if in_place == len(tr):
+            return
+        self.grad_pack_launches += 1
+        if in_place == 0:
+            torch.cat([p.grad.reshape(-1) for p in tr], out=self._flat_grad)
+        else:   # some already live in the buffer: pack through a temporary (cat must not read what it overwrites)
+            self._flat_grad.copy_(torch.cat([p.grad.reshape(-1) for p in tr]))
         off = 0
         for p in tr:
             p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
@@ -309,7 +331,8 @@ class QMixLearner:
             # the loss kernel also produces dL/dQ_tot: it seeds the backward pass directly (no ones-fill / multiply)
             loss, eval_mean, target_mean, gy = ops.td_loss_and_grad(
                 eval_q_tot, target_q_tot, st["reward"], st["terminated"], st["filled"], self.args.gamma, T - 1, 1)
-            with ops.deferred_wgrad():   # the six weight gradients: one grouped launch pair after the chain
+            # the weight gradients: one grouped launch pair after the chain, written into the flat gradient vector
+            with ops.deferred_wgrad(grad_dst=getattr(self, "_grad_dst", None)):
                 eval_q_tot.backward(gy)
         else:
             loss, eval_mean, target_mean = ops.td_loss_full(eval_q_tot, target_q_tot, st["reward"], st["terminated"],

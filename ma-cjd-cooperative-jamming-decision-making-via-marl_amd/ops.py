@@ -12,6 +12,7 @@ import ctypes
 import os
 from typing import Optional, Tuple
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -541,6 +542,24 @@ def gather_rows(idx, srcs, dsts):
 # Linear with a split-K MFMA weight / bias gradient (csrc/macjd_wgrad.hip)
 _DEFERRED_WGRAD = None   # list of (WgradIO, keep-alive tensors) while a ``deferred_wgrad`` context is active
 _DEFERRED_POST = None    # callables run right after the grouped launches of that context
+_GRAD_DST = None         # {grad_key: destination tensor} of the active context (see deferred_wgrad.__init__)
+_DEFERRED_SEEN = None    # grad_keys with a recorded (or already flushed) gradient in the active context
+
+
+def grad_key(t):
+    """Identity of a parameter (or of a merged view over several) for the gradient-destination map."""
+    return None if t is None else (t.data_ptr(), t.numel())
+
+
+def _grad_dst(key, shape):
+    """A FRESH view (autograd must be its only owner, see linear_wgrad) of the registered destination, or None."""
+    if not _GRAD_DST or key is None:
+        return None
+    dst = _GRAD_DST.get(key)
+    if dst is None or dst.numel() != int(np.prod(shape)) or not dst.is_contiguous():
+        return None
+    del _GRAD_DST[key]   # once per backward pass: a parameter used twice gets an ordinary second gradient, which
+    return dst.view(shape)   # autograd then accumulates (in place) into the first
 
 
 class deferred_wgrad:
@@ -548,18 +567,28 @@ class deferred_wgrad:
     the problem is recorded (its operands kept alive) and ALL recorded problems run as one partial-products launch +
     one reduce launch when the context exits (same arithmetic and summation order per problem).  They only feed
     ``.grad`` and nothing in the backward pass waits for them.  The gradient tensors handed to autograd are filled by
-    the flush: read them only after the context — and let autograd (or the caller) be their only owner until then."""
+    the flush: read them only after the context — and let autograd (or the caller) be their only owner until then.
+    A parameter used twice in the graph is handled (its second gradient forces the recorded ones out first)."""
+
+    def __init__(self, grad_dst=None):
+        # {grad_key(parameter): preallocated gradient tensor of the parameter's shape}: inside the context the
+        # weight / bias gradients of those parameters are written straight into these tensors (slices of the
+        # learner's flat gradient vector) and autograd receives fresh views of them — no packing copy afterwards
+        self._grad_dst = grad_dst
 
     def __enter__(self):
-        global _DEFERRED_WGRAD, _DEFERRED_POST
+        global _DEFERRED_WGRAD, _DEFERRED_POST, _GRAD_DST, _DEFERRED_SEEN
         self._prev, _DEFERRED_WGRAD = _DEFERRED_WGRAD, []
         self._prev_post, _DEFERRED_POST = _DEFERRED_POST, []
+        self._prev_dst, _GRAD_DST = _GRAD_DST, (dict(self._grad_dst) if self._grad_dst else None)
+        self._prev_seen, _DEFERRED_SEEN = _DEFERRED_SEEN, set()
         return self
 
     def __exit__(self, *exc):
-        global _DEFERRED_WGRAD, _DEFERRED_POST
+        global _DEFERRED_WGRAD, _DEFERRED_POST, _GRAD_DST, _DEFERRED_SEEN
         pending, _DEFERRED_WGRAD = _DEFERRED_WGRAD, self._prev
         post, _DEFERRED_POST = _DEFERRED_POST, self._prev_post
+        _GRAD_DST, _DEFERRED_SEEN = self._prev_dst, self._prev_seen
         self._flush(exc, pending)
         if exc[0] is None:
             for fn in post:      # launches that consume the flushed products (e.g. LayerNorm parameter gradients)
@@ -579,24 +608,44 @@ class deferred_wgrad:
                                   "macjd_linear_wgrad_many")
 
 
-def linear_wgrad(gout, inp, want_bias=True):
-    """dW [M,N] = gout[K,M]^T inp[K,N], db [M] = column sums of gout (HIP device, float32, row-strided inputs)."""
+def linear_wgrad(gout, inp, want_bias=True, w_key=None, b_key=None, need=(True, True)):
+    """dW [M,N] = gout[K,M]^T inp[K,N], db [M] = column sums of gout (HIP device, float32, row-strided inputs).
+    ``w_key`` / ``b_key`` = grad_key of the parameters these are the gradients of: when the active ``deferred_wgrad``
+    context maps them to destinations, the results are written there.  ``need`` = which of (dW, db) the caller hands
+    to autograd for a tensor that requires grad; a result autograd will drop is kept alive until the deferred launch
+    has written it (its memory must not be reused before)."""
     lib = _native.load()
     gout, inp = _f32c(gout), _f32c(inp)
     K, M = gout.shape
     N = inp.shape[1]
-    dW = torch.empty((M, N), dtype=torch.float32, device=gout.device)
-    db = torch.empty((M,), dtype=torch.float32, device=gout.device) if want_bias else None
+    dW = _grad_dst(w_key, (M, N))
+    if dW is None:
+        dW = torch.empty((M, N), dtype=torch.float32, device=gout.device)
+    db = None
+    if want_bias:
+        db = _grad_dst(b_key, (M,))
+        if db is None:
+            db = torch.empty((M,), dtype=torch.float32, device=gout.device)
     ws = torch.empty(int(lib.macjd_linear_wgrad_workspace_floats(K, M, N)), dtype=torch.float32, device=gout.device)
     io = _native.WgradIO()
     io.K, io.M, io.N = K, M, N
     io.gout, io.gout_ld, io.inp, io.inp_ld = gout.data_ptr(), gout.stride(0), inp.data_ptr(), inp.stride(0)
     io.dW, io.dw_ld, io.db, io.workspace = dW.data_ptr(), dW.stride(0), (db.data_ptr() if want_bias else None), ws.data_ptr()
-    if _DEFERRED_WGRAD is not None:
+    if _DEFERRED_WGRAD is not None and any(k is not None and k in _DEFERRED_SEEN for k in (w_key, b_key)):
+        # a parameter used twice in the graph: autograd ADDS this gradient to the first one as soon as it gets it, so
+        # the recorded ones must be in memory by then — run them now, and this one immediately
+        pending, posts = list(_DEFERRED_WGRAD), list(_DEFERRED_POST)
+        del _DEFERRED_WGRAD[:], _DEFERRED_POST[:]
+        deferred_wgrad._flush((None, None, None), pending)
+        for fn in posts:
+            fn()
+    elif _DEFERRED_WGRAD is not None:
+        _DEFERRED_SEEN.update(k for k in (w_key, b_key) if k is not None)
         # keep the OPERANDS and the workspace alive until the flush, but hold no reference to dW / db: autograd's
         # AccumulateGrad only adopts a gradient tensor it is the sole owner of — with a second reference it would
         # clone the still unfilled buffer into .grad right away (the flush would then fill a tensor nobody reads)
-        _DEFERRED_WGRAD.append((io, (ws, gout, inp)))
+        unowned = tuple(t for t, n in ((dW, need[0]), (db, need[1])) if t is not None and not n)
+        _DEFERRED_WGRAD.append((io, (ws, gout, inp) + unowned))
         return dW, db
     with torch.cuda.device(gout.device):
         _native.check(lib.macjd_linear_wgrad(ctypes.byref(io), _stream(gout)), "macjd_linear_wgrad")
@@ -610,7 +659,7 @@ class _LinearSplitK(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
+        ctx.has_bias, ctx.b_key = bias is not None, grad_key(bias)
         return F.linear(x, weight, bias)
 
     @staticmethod
@@ -619,7 +668,9 @@ class _LinearSplitK(torch.autograd.Function):
         gx = gy.matmul(weight) if ctx.needs_input_grad[0] else None
         gW = gb = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gW, gb = linear_wgrad(gy.reshape(-1, gy.shape[-1]), x.reshape(-1, x.shape[-1]), want_bias=ctx.has_bias)
+            gW, gb = linear_wgrad(gy.reshape(-1, gy.shape[-1]), x.reshape(-1, x.shape[-1]), want_bias=ctx.has_bias,
+                                  w_key=grad_key(weight), b_key=ctx.b_key,
+                                  need=(ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]))
         return gx, gW, (gb if ctx.has_bias else None)
 
 
@@ -631,14 +682,14 @@ class _MergedLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_cat, b_cat, *params):
         ctx.save_for_backward(x, w_cat)
-        ctx.sizes = [p.shape[0] for p in params[:len(params) // 2]]
+        ctx.sizes, ctx.b_key = [p.shape[0] for p in params[:len(params) // 2]], grad_key(b_cat)
         return F.linear(x, w_cat, b_cat)
 
     @staticmethod
     def backward(ctx, gy):
         x, w_cat = ctx.saved_tensors
         gx = gy.matmul(w_cat) if ctx.needs_input_grad[0] else None
-        gW, gb = linear_wgrad(gy, x, want_bias=True)
+        gW, gb = linear_wgrad(gy, x, want_bias=True, w_key=grad_key(w_cat), b_key=ctx.b_key)
         return (gx, None, None) + tuple(gW.split(ctx.sizes, 0)) + tuple(gb.split(ctx.sizes, 0))
 
 
@@ -679,17 +730,21 @@ class _NormMergedLinear(torch.autograd.Function):
         _, s_, _, _, xhat = _layernorm_launch(x, gamma, beta, eps, want_xhat=True)
         ctx.save_for_backward(s_, xhat, w_cat)
         ctx.sizes = [p.shape[0] for p in params[:len(params) // 2]]
+        ctx.keys = (grad_key(b_cat), grad_key(gamma), grad_key(beta))
         return F.linear(s_, w_cat, b_cat)
 
     @staticmethod
     def backward(ctx, gy):
         s_, xhat, w_cat = ctx.saved_tensors
         assert not ctx.needs_input_grad[0], "norm_merged_linear is for inputs that need no gradient"
-        gW, gb = linear_wgrad(gy, s_, want_bias=True)
+        gW, gb = linear_wgrad(gy, s_, want_bias=True, w_key=grad_key(w_cat), b_key=ctx.keys[0])
         G, _ = linear_wgrad(gy, xhat, want_bias=False)
         K = w_cat.shape[1]
-        dgamma = torch.empty(K, dtype=torch.float32, device=gy.device)
-        dbeta = torch.empty(K, dtype=torch.float32, device=gy.device)
+        dgamma, dbeta = _grad_dst(ctx.keys[1], (K,)), _grad_dst(ctx.keys[2], (K,))
+        if dgamma is None:
+            dgamma = torch.empty(K, dtype=torch.float32, device=gy.device)
+        if dbeta is None:
+            dbeta = torch.empty(K, dtype=torch.float32, device=gy.device)
         io = _native.LnParamIO()
         io.C, io.K = w_cat.shape[0], K
         io.W, io.w_ld, io.G, io.g_ld = w_cat.data_ptr(), w_cat.stride(0), G.data_ptr(), G.stride(0)
@@ -815,7 +870,7 @@ class _SplitRelu(torch.autograd.Function):
         outs = list(act.split(widths, dim=1))
         if dot_k >= 0:
             ctx.save_for_backward(act, dot_w)
-            ctx.has_bias = dot_b is not None
+            ctx.has_bias, ctx.b_key = dot_b is not None, grad_key(dot_b)
             outs[dot_k] = _rowdot_launch(outs[dot_k], dot_w, dot_b)
         else:
             ctx.save_for_backward(act)
@@ -834,7 +889,8 @@ class _SplitRelu(torch.autograd.Function):
             outer[k] = dot_w
             if grads[k] is not None and (ctx.needs_input_grad[4] or (ctx.has_bias and ctx.needs_input_grad[5])):
                 h = act.split(ctx.widths, dim=1)[k]
-                gW, gb = linear_wgrad(grads[k].reshape(-1, 1), h, want_bias=ctx.has_bias)
+                gW, gb = linear_wgrad(grads[k].reshape(-1, 1), h, want_bias=ctx.has_bias, w_key=grad_key(dot_w), b_key=ctx.b_key,
+                                      need=(ctx.needs_input_grad[4], ctx.has_bias and ctx.needs_input_grad[5]))
         gout = _splitrelu_backward_launch(act, ctx.widths, ctx.Cp, grads, grads[nb] if ctx.Cp else None, outer)
         return gout, None, None, None, gW, (gb if k >= 0 and ctx.has_bias else None)
 
@@ -882,7 +938,7 @@ class _RowDot(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
+        ctx.has_bias, ctx.b_key = bias is not None, grad_key(bias)
         return _rowdot_launch(x, weight, bias)
 
     @staticmethod
@@ -891,7 +947,9 @@ class _RowDot(torch.autograd.Function):
         gx = gy * weight.reshape(1, -1) if ctx.needs_input_grad[0] else None
         gW = gb = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gW, gb = linear_wgrad(gy.reshape(-1, 1), x.reshape(-1, x.shape[-1]), want_bias=ctx.has_bias)
+            gW, gb = linear_wgrad(gy.reshape(-1, 1), x.reshape(-1, x.shape[-1]), want_bias=ctx.has_bias,
+                                  w_key=grad_key(weight), b_key=ctx.b_key,
+                                  need=(ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]))
         return gx, gW, (gb if ctx.has_bias else None)
 
 
@@ -909,6 +967,7 @@ class _LinearReluSplitK(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         y = torch._addmm_activation(bias, x, weight.t(), use_gelu=False)
         ctx.save_for_backward(x, weight, y)
+        ctx.b_key = grad_key(bias)
         return y
 
     @staticmethod
@@ -916,7 +975,8 @@ class _LinearReluSplitK(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         g = torch.ops.aten.threshold_backward(gy, y, 0.0)
         gx = g.matmul(weight) if ctx.needs_input_grad[0] else None
-        gW, gb = linear_wgrad(g, x, want_bias=True)
+        gW, gb = linear_wgrad(g, x, want_bias=True, w_key=grad_key(weight), b_key=ctx.b_key,
+                              need=(ctx.needs_input_grad[1], ctx.needs_input_grad[2]))
         return gx, gW, gb
 
 
@@ -942,7 +1002,7 @@ class _LinearReluRowDot(torch.autograd.Function):
     def forward(ctx, x, w1, b1, w2, b2):
         y = torch._addmm_activation(b1, x, w1.t(), use_gelu=False)
         ctx.save_for_backward(x, w1, y, w2)
-        ctx.has_b2 = b2 is not None
+        ctx.has_b2, ctx.b1_key, ctx.b2_key = b2 is not None, grad_key(b1), grad_key(b2)
         return _rowdot_launch(y, w2, b2)
 
     @staticmethod
@@ -950,8 +1010,13 @@ class _LinearReluRowDot(torch.autograd.Function):
         x, w1, y, w2 = ctx.saved_tensors
         g = _splitrelu_backward_launch(y, [y.shape[1]], 0, [gq], None, [w2])
         gx = g.matmul(w1) if ctx.needs_input_grad[0] else None
-        gW1, gb1 = linear_wgrad(g, x, want_bias=True)
-        gW2, gb2 = linear_wgrad(gq.reshape(-1, 1), y, want_bias=ctx.has_b2)
+        nd = ctx.needs_input_grad
+        gW1 = gb1 = gW2 = gb2 = None
+        if nd[1] or nd[2]:
+            gW1, gb1 = linear_wgrad(g, x, want_bias=True, w_key=grad_key(w1), b_key=ctx.b1_key, need=(nd[1], nd[2]))
+        if nd[3] or (ctx.has_b2 and nd[4]):
+            gW2, gb2 = linear_wgrad(gq.reshape(-1, 1), y, want_bias=ctx.has_b2, w_key=grad_key(w2), b_key=ctx.b2_key,
+                                    need=(nd[3], ctx.has_b2 and nd[4]))
         return gx, gW1, gb1, gW2, (gb2 if ctx.has_b2 else None)
 
 

@@ -372,6 +372,9 @@ def test_graphed_train_equals_eager_train(T, N, B, steps, single, monkeypatch):
         for k in se:
             assert sg[k] == pytest.approx(se[k], rel=1e-4, abs=1e-6), (step, k)
     assert graphed.train_step == eager.train_step == steps and graphed.last_target_update_step == 3 * (steps // 3)
+    # full-size batches: every weight gradient was written straight into the flat gradient vector (no packing copy in
+    # the captured graph); the small size runs on stock autograd gradients, which are packed
+    assert (graphed.grad_pack_launches == 0) == (B * (T + 1) * 3 >= 1024), graphed.grad_pack_launches
     # weights after the Adam steps (lr 5e-4): Adam's m / sqrt(v) amplifies summation-order noise of near-zero gradient
     # entries (the graphed path reduces over full-length rows), hence 2e-5 rather than float epsilon
     for (k, a), b in zip(mac_e.agent.state_dict().items(), mac_g.agent.state_dict().values()):
@@ -926,6 +929,55 @@ def test_deferred_weight_gradients_reach_dot_grad_exactly():
         got = run(True, scale)
         for a, b in zip(ref, got):
             assert torch.equal(a, b)
+
+
+def test_weight_gradients_written_into_registered_destinations():
+    """ops.deferred_wgrad(grad_dst=...): the gradients of the registered parameters land in the given tensors (slices
+    of one flat vector) and .grad aliases them — bitwise the ordinary gradients; a parameter used TWICE in the graph
+    still gets the sum (its second gradient forces the recorded ones out and is launched on the spot, autograd adds the
+    two), and a gradient autograd drops (frozen layer) is kept alive until the deferred launch has written it."""
+    from macjd_amd import ops
+    g = torch.Generator().manual_seed(6)
+    K = 3232
+    x = torch.randn(K, 46, generator=g).to(DEV)
+    W1 = (0.2 * torch.randn(64, 46, generator=g)).to(DEV).requires_grad_(True)
+    b1 = torch.randn(64, generator=g).to(DEV).requires_grad_(True)
+    W2 = (0.2 * torch.randn(1, 64, generator=g)).to(DEV).requires_grad_(True)
+    b2 = torch.zeros(1, device=DEV, requires_grad=True)
+    Ws = (0.2 * torch.randn(64, 64, generator=g)).to(DEV).requires_grad_(True)    # shared: used twice
+    W3, b3 = torch.eye(64, device=DEV), torch.zeros(64, device=DEV)               # frozen layer: no destination
+    params = [W1, b1, W2, b2, Ws]
+    flat = torch.full((sum(p_.numel() for p_ in params),), 7.0, device=DEV)
+    dst, off = {}, 0
+    for p_ in params:
+        dst[ops.grad_key(p_)] = flat[off:off + p_.numel()].view_as(p_)
+        off += p_.numel()
+
+    def run(use_dst, scale):
+        for p_ in params:
+            p_.grad = None
+        h = ops.linear_relu(x * scale, W1, b1)
+        h = ops.linear(ops.linear(h, Ws, None), Ws, None)
+        y = ops.linear_relu_dot(h, W3, b3, W2, b2)
+        if use_dst is None:
+            y.backward(torch.ones_like(y))      # ordinary backward: every weight gradient launched on the spot
+        else:
+            with ops.deferred_wgrad(grad_dst=dst if use_dst else None):
+                y.backward(torch.ones_like(y))
+        return [p_.grad for p_ in params]
+
+    for scale in (1.0, -0.6):
+        ref = [t.clone() for t in run(None, scale)]
+        for a, b in zip(ref, run(False, scale)):   # deferred, no destinations
+            assert torch.equal(a, b)
+        got = run(True, scale)
+        off = 0
+        for p_, a, b in zip(params, ref, got):
+            assert torch.equal(a, b)
+            if p_ is not Ws:    # (the sum for a shared parameter is a tensor of autograd's own)
+                assert b.data_ptr() == flat.data_ptr() + 4 * off, "gradient was not written in place"
+                assert torch.equal(flat[off:off + p_.numel()], a.reshape(-1))
+            off += p_.numel()
 
 
 def test_mlp_forward_pair_equals_two_single_launches():
