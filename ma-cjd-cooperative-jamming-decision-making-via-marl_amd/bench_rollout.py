@@ -91,7 +91,8 @@ def make_step(cli, sc, env, dev, rank, world, mode):
         learner._update_targets()
     runner = BatchedEpisodeRunner(env, mac, buf, args)
     T = args.episode_limit
-    np.random.seed(1234 + rank)  # replay sampling stream (np.random.choice, like the reference)
+    np.random.seed(1234 + rank)  # replay sampling stream of buffer.sample (np.random.choice, like the reference)
+    learner._sample_rng = np.random.default_rng(1234 + rank)   # ... and of the graphed update's own sampler
     use_graphs = not getattr(cli, "no_graphs", False)
     if mode == "train":
         runner.run(test_mode=False, sync_stats=False)  # untimed pre-fill of the replay buffer

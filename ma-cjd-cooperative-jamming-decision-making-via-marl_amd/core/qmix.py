@@ -69,6 +69,7 @@ class QMixLearner:
         self.last_target_update_step = 0
         self.train_step = 0
         self._flat_grad = None   # flat gradient vector (all-reduce buffer / input of the fused optimiser step)
+        self._sample_rng = np.random.default_rng(int(getattr(args, "seed", 0) or 0))   # train_from_buffer's episode sampler
         self.grad_pack_launches = 0   # updates whose gradients had to be packed into the flat vector by a copy
         self._flat_param = None
         if self.device.type == "cuda":
@@ -267,12 +268,17 @@ class QMixLearner:
         # tail launches on the side stream behind two events, a third stream for the actor / hyper-network work.
         # Forks taken from a forked stream crash hipStreamEndCapture (ROCm 7.2): every fork hangs off the capture's
         # origin stream.
-        def scan_chain():
+        def scan_only():
             gis = [m.agent.gru_input_transform(rows).view(B, T1, J, 3 * H) for m in macs]      # networks.py:100
-            h_alls = ops.gru_sequence_multi(gis, [m.agent.rnn.weight_hh for m in macs],
-                                            [m.agent.rnn.bias_hh for m in macs])                 # h_0 = 0, qmix.py:241
+            return ops.gru_sequence_multi(gis, [m.agent.rnn.weight_hh for m in macs],
+                                          [m.agent.rnn.bias_hh for m in macs])                   # h_0 = 0, qmix.py:241
+
+        def bases_of(h_alls):
             return [F.linear(h.reshape(n, H), hd[0][:, :H], m.agent.fc2_q_head[0].bias)
                     for m, h, hd in zip(macs, h_alls, heads)]
+
+        def scan_chain():
+            return bases_of(scan_only())
 
         def actor_chains():                                                                     # networks.py:127
             a0, a1 = macs[0].agent, macs[1].agent
@@ -299,21 +305,34 @@ class QMixLearner:
             layout = int(os.environ.get("MACJD_UPDATE_LAYOUT", "2"))   # A/B switch, see the table above
             ts.wait_stream(origin)                                                              # fork
             params = hyper = None
-            with torch.cuda.stream(ts), torch.no_grad():
-                bases = scan_chain()
-                if layout == 1:
-                    hyper = self.target_qmix_net.hyper_outputs(st["state"])
-                if layout == 2:
-                    params = actor_chains()
-            if params is None:
+            if layout == 3:
+                # as 2, but the origin stream's many short launches are ISSUED between the scan and the rest of the
+                # side stream: a replayed graph feeds its nodes to the GPU in capture order at a few us per node, so
+                # the long scan kernel should go out early and cover the time it takes to issue the origin branch
+                with torch.cuda.stream(ts), torch.no_grad():
+                    h_alls = scan_only()
+                eval_q_tot = eval_forward()
                 with torch.no_grad():
+                    hyper = self.target_qmix_net.hyper_outputs(st["state"])
+                with torch.cuda.stream(ts), torch.no_grad():
+                    bases = bases_of(h_alls)
                     params = actor_chains()
-            eval_q_tot = eval_forward()
+            else:
+                with torch.cuda.stream(ts), torch.no_grad():
+                    bases = scan_chain()
+                    if layout == 1:
+                        hyper = self.target_qmix_net.hyper_outputs(st["state"])
+                    if layout == 2:
+                        params = actor_chains()
+                if params is None:
+                    with torch.no_grad():
+                        params = actor_chains()
+                eval_q_tot = eval_forward()
             with torch.no_grad():
                 if hyper is None:
                     hyper = self.target_qmix_net.hyper_outputs(st["state"])
                 origin.wait_stream(ts)                                                          # join
-                for t_ in list(bases) + ([*hyper] if layout == 1 else []) + ([*params] if layout == 2 else []):
+                for t_ in list(bases) + ([*hyper] if layout == 1 else []) + ([*params] if layout >= 2 else []):
                     if torch.is_tensor(t_):
                         t_.record_stream(origin)
                 target_q_tot = target_q_tot_of(bases, params, hyper)
@@ -390,6 +409,7 @@ class QMixLearner:
             raise RuntimeError("enable_graphs needs the learner on a HIP device")
         self._g_buffer, self._g_B, self._g_T = buffer, int(batch_size), int(buffer.episode_limit)
         self._g_idx = torch.zeros(self._g_B, dtype=torch.int64, device=self.device)
+        self._g_idx_ring = [(torch.zeros(self._g_B, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(8)]
         if buffer.current_size < 1:
             raise RuntimeError("enable_graphs: the replay buffer is empty")
 
@@ -453,12 +473,24 @@ class QMixLearner:
         if buf is None:
             raise RuntimeError("call enable_graphs(buffer, batch_size) first")
         if indices is None:
-            indices = np.random.choice(buf.current_size, self._g_B, replace=False)
+            # uniform without replacement like the reference's buffer.sample (replay_buffer.py:89), but from the
+            # learner's own numpy Generator: the legacy np.random.choice shuffles the whole population per call
+            # (~90 us for 8192 stored episodes — more host time than the rest of the update's launch), Generator.choice
+            # takes ~4 us.  EpisodeReplayBuffer.sample() keeps the reference's call.
+            indices = self._sample_rng.choice(buf.current_size, self._g_B, replace=False)
         indices = np.asarray(indices, dtype=np.int64)
         if len(indices) != self._g_B or int(buf.episode_lengths[indices].min()) != self._g_T:
             return self.train(buf.sample(len(indices), indices=indices), None, sync_stats=sync_stats)
         self.train_step += 1
-        self._g_idx.copy_(torch.from_numpy(indices))
+        # index upload from a small ring of pinned buffers: a copy from pageable memory makes the host wait for the
+        # stream (it could then never run ahead of the GPU and every node of the next replay would be issued just in
+        # time); a slot is reused only after the copy that read it has completed
+        k = self.train_step % len(self._g_idx_ring)
+        slot, ev = self._g_idx_ring[k]
+        ev.synchronize()
+        slot.numpy()[:] = indices
+        self._g_idx.copy_(slot, non_blocking=True)
+        ev.record()
         self._graph_a.replay()
         if not self._g_single:
             self._allreduce_grads()

@@ -55,3 +55,26 @@ for _ in range(50):
     a = time.perf_counter(); learner._graph_a.replay(); b = time.perf_counter(); torch.cuda.synchronize(); c = time.perf_counter()
     hs.append(b - a); ws.append(c - a)
 print(f"idle GPU: graph A replay() returns after {1e6 * sorted(hs)[len(hs) // 2]:.1f} us (median), work complete after {1e6 * sorted(ws)[len(ws) // 2]:.1f} us")
+
+# where the host time of one train_from_buffer() goes (same statements, timed one by one while the GPU is busy)
+import collections
+acc = collections.defaultdict(float)
+buf = learner._g_buffer
+M = 300
+for _ in range(M):
+    t = [time.perf_counter()]
+    idx = learner._sample_rng.choice(buf.current_size, learner._g_B, replace=False); t.append(time.perf_counter())
+    idx = np.asarray(idx, dtype=np.int64); ok = int(buf.episode_lengths[idx].min()) == learner._g_T; t.append(time.perf_counter())
+    learner.train_step += 1
+    slot, ev = learner._g_idx_ring[learner.train_step % len(learner._g_idx_ring)]
+    ev.synchronize(); t.append(time.perf_counter())
+    slot.numpy()[:] = idx; t.append(time.perf_counter())
+    learner._g_idx.copy_(slot, non_blocking=True); t.append(time.perf_counter())
+    ev.record(); t.append(time.perf_counter())
+    learner._graph_a.replay(); t.append(time.perf_counter())
+    learner._after_step(); t.append(time.perf_counter())
+    learner._pack_stats(*learner._g_out_a[:1], learner._g_out_b, *learner._g_out_a[1:], False); t.append(time.perf_counter())
+    for name, a, b in zip(("sample", "check", "event wait", "fill slot", "copy_", "event record", "replay", "after_step", "pack_stats"), t, t[1:]):
+        acc[name] += b - a
+torch.cuda.synchronize()
+print("host time per piece (us): " + ", ".join(f"{k} {1e6 * v / M:.1f}" for k, v in acc.items()))
