@@ -63,10 +63,11 @@ class RNNAgent(nn.Module):
     # Which chains go through the fused MFMA kernel (ops.mlp_forward) on a HIP device under no_grad.  Measured on MI355X
     # (bench.py, episode-aligned accounting): actor 46-128-128-9 at 12 288 rows: 15.5 us fused vs 39 us as 3 library
     # GEMMs + 3 activation launches; fc1 + GRU input transform 46-64-192: one 14 us launch vs 6.6 + 4.8 + 11.1 us in the
-    # rollout step's serial chain (rollout 0.0793 -> 0.0744 ms / step), no gain for the learner's 9 696-row
-    # time-parallel transform (train 0.502 vs 0.505 ms), which therefore stays on library GEMMs.
+    # rollout step's serial chain (rollout 0.0793 -> 0.0744 ms / step); the learner's 9 696-row time-parallel transform
+    # of both controllers as ONE pair launch instead of four GEMMs: no gain while the update was fed to the GPU just in
+    # time (0.502 vs 0.505 ms), 0.3636 -> 0.356 ms once the host ran ahead (3 runs each, +-0.1 %).
     fused_actor = os.environ.get("MACJD_FUSED_ACTOR", "1") != "0"
-    fused_gi = os.environ.get("MACJD_FUSED_GI", "0") != "0"                   # learner's time-parallel transform
+    fused_gi = os.environ.get("MACJD_FUSED_GI", "1") != "0"                   # learner's time-parallel transform
     fused_gi_step = os.environ.get("MACJD_FUSED_GI_STEP", "1") != "0"         # the rollout step (RNNAgent.forward)
 
     def _fused_ok(self, t):

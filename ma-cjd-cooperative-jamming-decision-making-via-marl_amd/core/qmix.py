@@ -269,7 +269,12 @@ class QMixLearner:
         # Forks taken from a forked stream crash hipStreamEndCapture (ROCm 7.2): every fork hangs off the capture's
         # origin stream.
         def scan_only():
-            gis = [m.agent.gru_input_transform(rows).view(B, T1, J, 3 * H) for m in macs]      # networks.py:100
+            a0, a1 = macs[0].agent, macs[1].agent
+            if rows.is_cuda and a0.fused_gi and a1.fused_gi and not torch.is_grad_enabled():
+                # fc1 -> ReLU -> W_ih of both controllers: one launch of the dense-chain kernel
+                gis = [g.view(B, T1, J, 3 * H) for g in ops.mlp_forward_pair(rows, a0.gi_layers(), rows, a1.gi_layers())]
+            else:
+                gis = [m.agent.gru_input_transform(rows).view(B, T1, J, 3 * H) for m in macs]  # networks.py:100
             return ops.gru_sequence_multi(gis, [m.agent.rnn.weight_hh for m in macs],
                                           [m.agent.rnn.bias_hh for m in macs])                   # h_0 = 0, qmix.py:241
 
