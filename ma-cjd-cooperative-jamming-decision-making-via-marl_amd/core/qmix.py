@@ -263,6 +263,9 @@ class QMixLearner:
         # box, median ms / step):  0 = actor chains + target hyper-networks on this stream      0.3855
         #                          1 = target hyper-networks behind the scan chain instead      0.3742
         #                          2 = actor chains behind the scan chain instead (default)     0.3693
+        # re-measured once the host ran ahead of the GPU (4 runs each, +-0.3 %): 0: 0.3569, 1: 0.3696, 2: 0.3512,
+        # 3 (= 2 with the origin stream's launches captured between the scan and the rest of the side stream): 0.3514,
+        # 4 (actor chains AND target hyper-networks behind the scan chain): 0.3902 vs 0.3517 for 2.
         # (timeline before: side stream done at ~120 us, this stream at ~220 us; the branch a replayed graph starts
         # second begins 30 - 50 us late whatever it holds).  Variants measured equal within noise earlier: the Q-head /
         # tail launches on the side stream behind two events, a third stream for the actor / hyper-network work.
@@ -327,8 +330,10 @@ class QMixLearner:
                     bases = scan_chain()
                     if layout == 1:
                         hyper = self.target_qmix_net.hyper_outputs(st["state"])
-                    if layout == 2:
+                    if layout in (2, 4):
                         params = actor_chains()
+                    if layout == 4:
+                        hyper = self.target_qmix_net.hyper_outputs(st["state"])
                 if params is None:
                     with torch.no_grad():
                         params = actor_chains()
@@ -337,7 +342,7 @@ class QMixLearner:
                 if hyper is None:
                     hyper = self.target_qmix_net.hyper_outputs(st["state"])
                 origin.wait_stream(ts)                                                          # join
-                for t_ in list(bases) + ([*hyper] if layout == 1 else []) + ([*params] if layout >= 2 else []):
+                for t_ in list(bases) + ([*hyper] if layout in (1, 4) else []) + ([*params] if layout >= 2 else []):
                     if torch.is_tensor(t_):
                         t_.record_stream(origin)
                 target_q_tot = target_q_tot_of(bases, params, hyper)
