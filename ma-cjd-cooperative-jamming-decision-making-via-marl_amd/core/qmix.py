@@ -253,10 +253,10 @@ class QMixLearner:
 
         # Two streams inside the (captured) update, balanced by hand from the kernel timeline
         # (scripts/timeline_update.py):
-        #   side stream   (no grad) fc1 / GRU-input GEMMs of both controllers -> the fused scan (~65 us latency chain)
-        #                 -> Q-head base GEMMs -> the frozen actor chains of both controllers (one launch)
-        #   this stream   (autograd) Q-head on the STORED hidden states + eval mixer -> (no grad) the target mixer's
-        #                 hyper-networks (they read only the state)
+        #   side stream   (no grad) fc1 -> W_ih of both controllers (one dense-chain pair launch) -> the fused scan
+        #                 (~55 us latency chain) -> Q-head base GEMMs -> the target controller's frozen actor chain
+        #   this stream   (no grad) the eval controller's frozen actor chain -> (autograd) Q-head on the STORED hidden
+        #                 states + eval mixer -> (no grad) the target mixer's hyper-networks (they read only the state)
         #   ONE join, then on this stream the two Double-DQN Q-head launches, the target mixer tail and the loss.
         # Autograd only ever sees this stream.  The split took the step from 0.565 to 0.490 ms when it was introduced.
         # MACJD_UPDATE_LAYOUT picks where the two movable no-grad pieces run (10 interleaved bench runs each on one
@@ -266,6 +266,10 @@ class QMixLearner:
         # re-measured once the host ran ahead of the GPU (4 runs each, +-0.3 %): 0: 0.3569, 1: 0.3696, 2: 0.3512,
         # 3 (= 2 with the origin stream's launches captured between the scan and the rest of the side stream): 0.3514,
         # 4 (actor chains AND target hyper-networks behind the scan chain): 0.3902 vs 0.3517 for 2.
+        # 5 (= 2 + the Double-DQN launches at the end of the side stream): 0.3514 vs 0.3519 — the side stream is the
+        # longer branch in the un-profiled run.  6 (target actor chain behind the scan chain, eval actor chain FIRST on
+        # this stream, two single launches; default): 0.3469 vs 0.3523 for 2.  7 (= 6 with this stream's actor chain
+        # issued last): 0.3570 vs 0.3463 for 6.
         # (timeline before: side stream done at ~120 us, this stream at ~220 us; the branch a replayed graph starts
         # second begins 30 - 50 us late whatever it holds).  Variants measured equal within noise earlier: the Q-head /
         # tail launches on the side stream behind two events, a third stream for the actor / hyper-network work.
@@ -294,9 +298,12 @@ class QMixLearner:
                 return list(ops.mlp_forward_pair(rows, a0.actor_layers(), rows, a1.actor_layers()))
             return [m.agent.actor_forward(rows) for m in macs]
 
-        def target_q_tot_of(bases, params, hyper):
+        def double_q(bases, params):
             # a* = argmax_a Q_eval (no mask, qmix.py:138-143), Q_target(a*) (qmix.py:147): two launches, [B,T+1,J]
-            tq = ops.qhead_double_q(bases[1], params[1], heads[1], bases[0], params[0], heads[0], H, A).view(B, T1, J)
+            return ops.qhead_double_q(bases[1], params[1], heads[1], bases[0], params[0], heads[0], H, A).view(B, T1, J)
+
+        def target_q_tot_of(bases, params, hyper, tq=None):
+            tq = double_q(bases, params) if tq is None else tq
             return self.target_qmix_net(tq, st["state"], hyper=hyper)                          # [B,T+1,1], qmix.py:151
 
         def eval_forward():
@@ -310,9 +317,9 @@ class QMixLearner:
             if getattr(self, "_target_stream", None) is None:
                 self._target_stream = torch.cuda.Stream(device=dev)
             ts = self._target_stream
-            layout = int(os.environ.get("MACJD_UPDATE_LAYOUT", "2"))   # A/B switch, see the table above
+            layout = int(os.environ.get("MACJD_UPDATE_LAYOUT", "6"))   # A/B switch, see the table above
             ts.wait_stream(origin)                                                              # fork
-            params = hyper = None
+            params = hyper = tq = None
             if layout == 3:
                 # as 2, but the origin stream's many short launches are ISSUED between the scan and the rest of the
                 # side stream: a replayed graph feeds its nodes to the GPU in capture order at a few us per node, so
@@ -330,22 +337,33 @@ class QMixLearner:
                     bases = scan_chain()
                     if layout == 1:
                         hyper = self.target_qmix_net.hyper_outputs(st["state"])
-                    if layout in (2, 4):
+                    if layout in (2, 4, 5):
                         params = actor_chains()
+                    if layout in (6, 7):   # the two actor chains split between the streams (two single launches)
+                        p_side = macs[0].agent.actor_forward(rows)
+                    if layout == 5:   # the Double-DQN launches read only this stream's results
+                        tq = double_q(bases, params)
                     if layout == 4:
                         hyper = self.target_qmix_net.hyper_outputs(st["state"])
-                if params is None:
+                if layout == 6:
+                    with torch.no_grad():
+                        params = [p_side, macs[1].agent.actor_forward(rows)]
+                        p_side.record_stream(origin)
+                if params is None and layout != 7:
                     with torch.no_grad():
                         params = actor_chains()
                 eval_q_tot = eval_forward()
             with torch.no_grad():
                 if hyper is None:
                     hyper = self.target_qmix_net.hyper_outputs(st["state"])
+                if layout == 7:   # as 6, the origin stream's actor chain issued last
+                    params = [p_side, macs[1].agent.actor_forward(rows)]
+                    p_side.record_stream(origin)
                 origin.wait_stream(ts)                                                          # join
-                for t_ in list(bases) + ([*hyper] if layout in (1, 4) else []) + ([*params] if layout >= 2 else []):
+                for t_ in list(bases) + ([*hyper] if layout in (1, 4) else []) + ([*params] if layout >= 2 else []) + ([tq] if tq is not None else []):
                     if torch.is_tensor(t_):
                         t_.record_stream(origin)
-                target_q_tot = target_q_tot_of(bases, params, hyper)
+                target_q_tot = target_q_tot_of(bases, params, hyper, tq)
         else:
             with torch.no_grad():
                 target_q_tot = target_q_tot_of(scan_chain(), actor_chains(), self.target_qmix_net.hyper_outputs(st["state"]))
