@@ -51,7 +51,14 @@ def dist_setup(n_gpus):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 and os.environ.get("MACJD_BENCH_ONE_GPU_REHEARSAL") == "1":
+        # rehearsal of the N > 1 code path on a one-GPU box: every rank on cuda:0, gloo carrying the HIP tensors.
+        # Exercises sharding, broadcast, the two update graphs around the all-reduce, barriers and the max-over-ranks
+        # timing; the JSON line says so (config.rehearsal) and its rate means nothing.
+        local = 0
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo")
+    elif world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -301,6 +308,8 @@ def main():
                        "mode": mode, "per_gpu_env_steps_per_s": round(E * args.steps / dt, 1), **extra},
             "roofline": roofline,
         }
+        if world > 1 and os.environ.get("MACJD_BENCH_ONE_GPU_REHEARSAL") == "1":
+            res["config"]["rehearsal"] = "all ranks on ONE GPU over gloo: code-path check only, not a measurement"
         if roofline_mfma is not None:
             res["roofline_mfma"] = roofline_mfma
         if sweep:
