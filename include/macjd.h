@@ -169,9 +169,11 @@ int macjd_env_reset(const macjd_scenario* s, int64_t n_envs, uint8_t* track, int
 /* replaces ElectromagneticEnvironment.step (environment.py:221-477) */
 int macjd_env_step(const macjd_scenario* s, const macjd_step_io* io, void* hip_stream);
 
-/* timing helper for bench.py: enqueue `iters` back-to-back env_step launches on `hip_stream`
-   bracketed by HIP events recorded on that same stream, wait, and return the average
-   milliseconds per launch in *ms_per_launch. */
+/* timing helper for bench.py: `iters` back-to-back env_step launches, replayed from one HIP graph on a private
+   stream after the work queued on `hip_stream` has finished (as the benchmark's rollout replays them, so the
+   host's enqueue rate does not enter; issued directly on `hip_stream` if the capture is refused), bracketed by
+   HIP events recorded on the stream the launches run on; waits and returns the average milliseconds per
+   launch in *ms_per_launch. */
 int macjd_env_step_timed(const macjd_scenario* s, const macjd_step_io* io, int iters,
                          void* hip_stream, float* ms_per_launch);
 
