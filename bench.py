@@ -100,7 +100,7 @@ def pmc_traffic(J, R, E, per_env=False):
     """HBM bytes per env_step launch from the committed rocprofv3 PMC summary (profiles/), collected in
     separate --pmc passes and corrected as MI355X_MICROARCH.md prescribes; None when no matching run."""
     import glob
-    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_env_step_pmc.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_env_step*_pmc.json")), reverse=True):
         try:
             d = json.load(open(f))
         except Exception:

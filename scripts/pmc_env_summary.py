@@ -1,0 +1,47 @@
+"""Summarise rocprofv3 --pmc passes of the env-step kernels into the JSON that bench.py's `roofline.traffic` reads
+(profiles/r*_env_step_pmc.json).  One directory per (E, counter) pass, named <out>/E<E>_<COUNTER>/ and produced by
+
+  cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --pmc FETCH_SIZE -d <out>/E4096_FETCH_SIZE -o p -f csv -- python3 bench.py --mode env --batch-envs 4096 \
+      --steps 30 --warmup 5 --no-cpu-baseline          (and WRITE_SIZE; and --batch-envs 4194304)
+
+Counters come in KB; on gfx950 FETCH_SIZE reports half of the bytes of a coalesced streaming read
+(MI355X_MICROARCH.md, HBM section), so traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per dispatch (medians).
+Usage: python scripts/pmc_env_summary.py <out> <round-tag> > profiles/<round-tag>_env_step_pmc.json"""
+import csv
+import glob
+import json
+import os
+import statistics
+import sys
+
+out, tag = sys.argv[1], sys.argv[2]
+J, R, B_ALG = 3, 4, 85
+runs = {}
+for E, kern in ((4096, "env_step_slots_kernel"), (4194304, "env_step_kernel")):
+    rec = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        files = glob.glob(os.path.join(out, f"E{E}_{ctr}", "**", "*counter_collection.csv"), recursive=True)
+        vals = []
+        for f in files:
+            for r in csv.DictReader(open(f)):
+                if kern + "<" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                    vals.append(float(r["Counter_Value"]))
+        if not vals:
+            continue
+        rec[f"{ctr}_KB_median"], rec[f"{ctr}_n"] = statistics.median(vals), len(vals)
+    if len(rec) == 4:
+        rec["traffic_bytes_per_launch"] = int((2 * rec["FETCH_SIZE_KB_median"] + rec["WRITE_SIZE_KB_median"]) * 1024)
+        rec["algorithmic_bytes_per_launch"] = E * B_ALG
+        rec["traffic_over_algorithmic"] = round(rec["traffic_bytes_per_launch"] / (E * B_ALG), 4)
+        rec["kernel_name"] = kern
+        runs[str(E)] = rec
+print(json.dumps({
+    "round": tag, "kernel": f"macjd::env_step_slots_kernel<{J},{R}>",
+    "workload": f"{J} jammers / {R} radars, Philox in-kernel, info outputs on",
+    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (python3 bench.py --mode env --batch-envs E "
+              "--steps 30 --warmup 5); per-dispatch medians; unit KB; gfx950 correction per MI355X_MICROARCH.md section HBM: "
+              "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 (scripts/pmc_env_summary.py)",
+    "bytes_per_env_step_algorithmic": B_ALG,
+    "note": "E = 4096: (env x slot) kernel; E = 2^22: lane-per-env kernel (the default from 2^17 envs)",
+    "runs": runs}, indent=1))
