@@ -270,6 +270,7 @@ class QMixLearner:
         # longer branch in the un-profiled run.  6 (target actor chain behind the scan chain, eval actor chain FIRST on
         # this stream, two single launches; default): 0.3469 vs 0.3523 for 2.  7 (= 6 with this stream's actor chain
         # issued last): 0.3570 vs 0.3463 for 6.
+        # 8 (= 6 with the target mixer's hyper-networks issued before the eval forward): 0.3644 vs 0.3607 for 6.
         # (timeline before: side stream done at ~120 us, this stream at ~220 us; the branch a replayed graph starts
         # second begins 30 - 50 us late whatever it holds).  Variants measured equal within noise earlier: the Q-head /
         # tail launches on the side stream behind two events, a third stream for the actor / hyper-network work.
@@ -339,16 +340,18 @@ class QMixLearner:
                         hyper = self.target_qmix_net.hyper_outputs(st["state"])
                     if layout in (2, 4, 5):
                         params = actor_chains()
-                    if layout in (6, 7):   # the two actor chains split between the streams (two single launches)
+                    if layout in (6, 7, 8):   # the two actor chains split between the streams (two single launches)
                         p_side = macs[0].agent.actor_forward(rows)
                     if layout == 5:   # the Double-DQN launches read only this stream's results
                         tq = double_q(bases, params)
                     if layout == 4:
                         hyper = self.target_qmix_net.hyper_outputs(st["state"])
-                if layout == 6:
+                if layout in (6, 8):
                     with torch.no_grad():
                         params = [p_side, macs[1].agent.actor_forward(rows)]
                         p_side.record_stream(origin)
+                        if layout == 8:   # as 6, the target mixer's hyper-networks issued before the eval forward
+                            hyper = self.target_qmix_net.hyper_outputs(st["state"])
                 if params is None and layout != 7:
                     with torch.no_grad():
                         params = actor_chains()
