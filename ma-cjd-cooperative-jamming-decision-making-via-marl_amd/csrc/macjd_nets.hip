@@ -498,23 +498,7 @@ extern "C" int macjd_mixer_tail_backward(const macjd_mixer_io* io, void* hip_str
 // (M = 3168 for the reference batch).  Replaces ~13 elementwise / reduce launches forward and ~8 backward.
 namespace macjd {
 
-__device__ __forceinline__ float block_sum_1024(float v, float* smem) {
-    v = wave_sum(v);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) smem[wave] = v;
-    __syncthreads();
-    float t = (threadIdx.x < (blockDim.x >> 6)) ? smem[threadIdx.x] : 0.0f;
-    if (wave == 0) {
-        t = wave_sum(t);
-        if (lane == 0) smem[0] = t;
-    }
-    __syncthreads();
-    return smem[0];
-}
-
 __global__ void __launch_bounds__(1024) td_loss_kernel(const macjd_tdloss_io io) {
-    __shared__ float smem[16];
     const int M = io.B * io.Tm1;
     float s_m = 0.f, s_e2 = 0.f, s_y = 0.f, s_t = 0.f;
     for (int i = threadIdx.x; i < M; i += blockDim.x) {
@@ -527,10 +511,28 @@ __global__ void __launch_bounds__(1024) td_loss_kernel(const macjd_tdloss_io io)
         const float e = (y - target) * m;                                // qmix.py:190-193
         s_m += m; s_e2 += e * e; s_y += y; s_t += target;
     }
-    const float tot_m = block_sum_1024(s_m, smem);
-    const float tot_e2 = block_sum_1024(s_e2, smem);
-    const float tot_y = block_sum_1024(s_y, smem);
-    const float tot_t = block_sum_1024(s_t, smem);
+    // the four block sums share their barriers (3 instead of 12); each sum is a
+    // wave_sum per wave, then a wave_sum over the per-wave values by wave 0
+    __shared__ float s4[4][16], tot4[4];
+    {
+        const float q[4] = {wave_sum(s_m), wave_sum(s_e2), wave_sum(s_y), wave_sum(s_t)};
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s4[k][wave] = q[k];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float t = (lane < (int)(blockDim.x >> 6)) ? s4[k][lane] : 0.0f;
+                t = wave_sum(t);
+                if (lane == 0) tot4[k] = t;
+            }
+        }
+        __syncthreads();
+    }
+    const float tot_m = tot4[0], tot_e2 = tot4[1], tot_y = tot4[2], tot_t = tot4[3];
     if (threadIdx.x == 0) {
         io.stats[0] = tot_e2 / tot_m;                                    // qmix.py:194
         io.stats[1] = tot_y / (float)M;
