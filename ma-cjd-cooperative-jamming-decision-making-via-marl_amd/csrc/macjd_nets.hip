@@ -11,9 +11,10 @@
 // as SGPR operands; the only vector memory traffic is the row's own base[H] (16-B loads), its P[A]
 // and the outputs.  The A accumulators live in registers (kernel templated on A).
 // At rollout / learner sizes (~10^4 rows) that is one wave per CU grinding through H x A serial
-// iterations, so for small batches a workgroup is HS = 4 waves over the SAME 64 rows, wave w taking the
-// hidden units [w H/4, (w+1) H/4) (weights stay wave-uniform); the partial sums meet in LDS and are
-// added in fixed wave order by wave 0, which then does the selection (14 us -> 6 us at 12 288 rows).
+// iterations, so for small batches a workgroup is HS = 8 waves over the SAME 64 rows, wave w taking the
+// hidden units [w H/8, (w+1) H/8) (weights stay wave-uniform); the partial sums meet in LDS and are
+// added in fixed wave order by wave 0, which then does the selection (14 us -> 6 us at 12 288 rows with HS = 4;
+// HS = 8 took the rollout step from 0.0739 to 0.0727 ms and the train step from 0.3756 to 0.3726 ms, HS = 2 is 3 % slower).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -36,10 +37,13 @@ __device__ __forceinline__ bool avail_at(const macjd_qhead_io& io, int64_t e, in
                                      : (((const int32_t*)io.avail)[off] != 0);
 }
 
-constexpr int QHEAD_HS = 4;   // hidden-unit splits (waves per 64 rows) of the small-batch launch
+#ifndef MACJD_QHEAD_HS
+#define MACJD_QHEAD_HS 8
+#endif
+constexpr int QHEAD_HS = MACJD_QHEAD_HS;   // hidden-unit splits (waves per 64 rows) of the small-batch launch
 
 template <int AT, int HS>
-__global__ void __launch_bounds__(256) qhead_select_kernel(const macjd_qhead_io io) {
+__global__ void __launch_bounds__(HS > 4 ? 64 * HS : 256) qhead_select_kernel(const macjd_qhead_io io) {
     constexpr int AMAX = AT ? AT : 64;
     const int A = AT ? AT : io.A;
     const int H = io.H;
