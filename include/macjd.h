@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MACJD_ABI_VERSION 2
+#define MACJD_ABI_VERSION 3
 #define MACJD_PE_ROWS(R, J) (6 * (R) + 3 * (J) + (J) * (R))
 
 #define MACJD_OK          0
@@ -107,8 +107,17 @@ typedef struct macjd_step_io {
 
     /* uniforms replacing np.random.rand() (environment.py:341,430): slot r<R = radar r's
        detection draw, slot R+k = k-th valid deception action (jammer order).  NULL → generated
-       in-kernel: Philox4x32-10, key = seed, counter = (env_offset+e, step_before, slot/2). */
+       in-kernel by Philox4x32-10: one block serves FOUR slots,
+         key     = (seed[31:0], seed[63:32] ^ genv[63:32]),            genv = env_offset + e
+         counter = (genv[31:0], episode[e], step_before, slot >> 2),
+         u       = (word[slot & 3] + 0.5) * 2^-32   (never 0, never 1),
+       so every (env, episode, step, slot) has its own value whatever the batch size, the sharding
+       over GPUs or the launch geometry. */
     const double* u;     int64_t u_se, u_sx;   /* [E,R+J] */
+    /* [E] episode index of each env, optional (NULL = 0): the reference draws fresh np.random.rand()
+       values in every episode; macjd_env_reset advances this counter (device memory, so a replayed
+       HIP graph advances it too) and the in-kernel generator keys on it.  Unused when u != NULL. */
+    const int32_t* episode;
 
     /* state, read-modify-write */
     uint8_t* track;      int64_t k_se, k_sx;   /* [E,R] 1 = TRACK, 0 = SEARCH (radar.py:90-119) */
@@ -162,9 +171,12 @@ int  macjd_scenario_dims(const macjd_scenario* s, int32_t* n_radars, int32_t* n_
                          int32_t* episode_limit);
 
 /* replaces ElectromagneticEnvironment.reset (environment.py:208-219): all radars SEARCH,
-   step counter 0.  mask (optional, [E] uint8) restricts the reset to envs with mask != 0. */
+   step counter 0.  mask (optional, [E] uint8) restricts the reset to envs with mask != 0.
+   episode (optional, [E] int32): the reset envs' episode index is incremented (see
+   macjd_step_io.episode). */
 int macjd_env_reset(const macjd_scenario* s, int64_t n_envs, uint8_t* track, int64_t k_se,
-                    int64_t k_sx, int32_t* step, const uint8_t* mask, void* hip_stream);
+                    int64_t k_sx, int32_t* step, const uint8_t* mask, int32_t* episode,
+                    void* hip_stream);
 
 /* replaces ElectromagneticEnvironment.step (environment.py:221-477) */
 int macjd_env_step(const macjd_scenario* s, const macjd_step_io* io, void* hip_stream);

@@ -14,7 +14,7 @@ LIB_NAME = "libmacjd_hip.so"
 # MACJD_LIB points at another build of the same sources (kernel A/B runs); the default is the in-tree library
 LIB_PATH = os.environ.get("MACJD_LIB") or os.path.join(_PKG_DIR, LIB_NAME)
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 STEP_ARITH_F64 = 1
 STEP_LANE_KERNEL = 2
 STEP_SLOT_KERNEL = 4
@@ -41,6 +41,7 @@ class StepIO(ctypes.Structure):
         ("T", ctypes.c_void_p), ("T_se", ctypes.c_int64), ("T_sx", ctypes.c_int64),
         ("P32", ctypes.c_void_p), ("P64", ctypes.c_void_p), ("P_se", ctypes.c_int64), ("P_sx", ctypes.c_int64),
         ("u", ctypes.c_void_p), ("u_se", ctypes.c_int64), ("u_sx", ctypes.c_int64),
+        ("episode", ctypes.c_void_p),
         ("track", ctypes.c_void_p), ("k_se", ctypes.c_int64), ("k_sx", ctypes.c_int64),
         ("step", ctypes.c_void_p),
         ("reward", ctypes.c_void_p), ("r_dpj", ctypes.c_void_p), ("terminated", ctypes.c_void_p),
@@ -237,7 +238,7 @@ def load() -> ctypes.CDLL:
     lib.macjd_scenario_dims.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int32)] * 3
     lib.macjd_env_reset.restype = ctypes.c_int
     lib.macjd_env_reset.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
-                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.macjd_env_step.restype = ctypes.c_int
     lib.macjd_env_step.argtypes = [ctypes.c_void_p, ctypes.POINTER(StepIO), ctypes.c_void_p]
     lib.macjd_env_step_timed.restype = ctypes.c_int

@@ -62,14 +62,55 @@ __device__ __forceinline__ double det_prob(double snr, double A, double c1, doub
     return (fabs(denB) < 1e-9) ? 0.0 : p;
 }
 
-template <bool PHILOX_ONLY = false>
-__device__ __forceinline__ double draw_uniform(const macjd_step_io& io, int64_t e, int slot, uint32_t step_before) {
-    if (!PHILOX_ONLY && io.u) return io.u[e * io.u_se + (int64_t)slot * io.u_sx];
-    const uint64_t genv = (uint64_t)(io.env_offset + e);
-    const Philox4 r = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), step_before, (uint32_t)(slot >> 1),
-                                    (uint32_t)io.seed, (uint32_t)(io.seed >> 32));
-    return (slot & 1) ? u53(r.v[2], r.v[3]) : u53(r.v[0], r.v[1]);
+// Uniform of (env e, slot) for the step that starts at `step_before` (include/macjd.h, macjd_step_io.u): supplied by the
+// caller, or word (slot & 3) of the env's Philox block (slot >> 2).  This on-demand form generates a whole block per
+// call; the kernels below generate each block they need ONCE per env-step and pick words out of it.
+__device__ __forceinline__ uint32_t philox_word(const Philox4& b, int w) {
+    uint32_t x = b.v[0];
+    x = (w == 1) ? b.v[1] : x;
+    x = (w == 2) ? b.v[2] : x;
+    x = (w == 3) ? b.v[3] : x;
+    return x;
 }
+template <bool PHILOX_ONLY = false, class IO = macjd_step_io>
+__device__ __forceinline__ double draw_uniform(const IO& io, int64_t e, uint32_t episode, int slot,
+                                               uint32_t step_before) {
+    if (!PHILOX_ONLY && io.u) return io.u[e * io.u_se + (int64_t)slot * io.u_sx];
+    const Philox4 r = env_philox_block(io.seed, (uint64_t)(io.env_offset + e), episode, step_before, (uint32_t)(slot >> 2));
+    return u32_mid(philox_word(r, slot & 3));
+}
+
+// Argument block of the production (FAST) variants: only what that configuration reads or writes, strides as int32.
+// A kernel taking the full macjd_step_io keeps ~95 SGPRs of arguments live next to ~70 SGPRs of wave-uniform table
+// constants and spills (88 SGPR spills = ~280 v_readlane / v_writelane VALU instructions per env-step at 3j/4r).
+struct FastStepIO {
+    int64_t n_envs, env_offset;
+    uint64_t seed;
+    const int32_t* T;
+    const float* P32;
+    const int32_t* episode;
+    uint8_t* track;
+    int32_t* step;
+    float* reward;
+    float* r_dpj;
+    uint8_t* terminated;
+    float* pd;
+    float* snr_with;
+    float* r_dpj_sum;
+    const double* pe_tables;
+    const uint8_t* pe_flags;
+    int64_t pe_stride;
+    int32_t T_se, T_sx, P_se, P_sx, k_se, k_sx, pd_se, pd_sx, sw_se, sw_sx, pe_tile;
+    // members of macjd_step_io this configuration never has (compile-time constants: the code paths fold away)
+    static constexpr const double* u = nullptr;
+    static constexpr int64_t u_se = 0, u_sx = 0;
+    static constexpr const double* P64 = nullptr;
+    static constexpr uint32_t flags = 0;
+    static constexpr double* out64 = nullptr;
+    static constexpr double* pd64 = nullptr;
+    static constexpr double* snr64 = nullptr;
+    static constexpr double* prj64 = nullptr;
+};
 
 // PE = per-env scenario tables (io.pe_tables, SoA [row][env]): every table read becomes a load from this lane's
 // column of the SoA (row index static for the per-jammer / per-radar loops, data-dependent for the reads gathered by
@@ -79,8 +120,8 @@ __device__ __forceinline__ double draw_uniform(const macjd_step_io& io, int64_t 
 // sizes the kernel is VALU-issue bound (PMC: ~1670 VALU instructions per 64-env iteration, VALU busy 73 % of the
 // kernel); the run-time mode tests cost ~50 uniform branches and, through the extra live pointers, ~400 SGPR spill
 // instructions (v_writelane / v_readlane) per iteration.
-template <int JT, int RT, bool PE, bool FAST>
-__global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restrict__ tb, const macjd_step_io io) {
+template <int JT, int RT, bool PE, bool FAST, class IO>
+__global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restrict__ tb, const IO io) {
     constexpr int NJ = JT ? JT : MAXJ;
     constexpr int NR = RT ? RT : MAXR;
     const int J = JT ? JT : tb->J;
@@ -108,10 +149,30 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
     const int32_t episode_limit = tb->episode_limit;
     const bool arith32 = FAST ? true : ((io.P32 != nullptr) && !(io.flags & MACJD_STEP_ARITH_F64));
 
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < io.n_envs;
-         e += (int64_t)gridDim.x * blockDim.x) {
+    auto env_step_one = [&](const int64_t e) {
         const int32_t step_before = io.step[e];
         const int32_t step_count = step_before + 1;  // environment.py:235
+        const uint32_t episode = io.episode ? (uint32_t)io.episode[e] : 0u;
+        // Monte-Carlo uniforms of this env-step (R radar slots, then one per valid deception action): every Philox
+        // block is generated once (ceil((R + J) / 4) blocks: 2 at 3j/4r) — the blocks holding deception slots before
+        // the jammer loop (a deception action selects word R + n_dec), the radar-only blocks after it, where the
+        // radar loop reads its words at compile-time indices (8 fewer live VGPRs across the jammer loop).
+        constexpr bool PRE = JT && RT;   // generic sizes generate a block on demand instead
+        constexpr int NBLK = PRE ? (NJ + NR + 3) / 4 : 1;
+        constexpr int DEC_B0 = NR >> 2;                       // first block with a deception slot
+        constexpr int RAD_LATE = PRE ? DEC_B0 : 0;            // blocks [0, RAD_LATE) hold radar slots only
+        uint32_t rw[NBLK * 4];
+        const bool own_rng = FAST || !io.u;
+        auto gen_blocks = [&](const int b0, const int b1) {
+#pragma unroll
+            for (int b = b0; b < b1; ++b) {
+                const Philox4 blk = env_philox_block(io.seed, (uint64_t)(io.env_offset + e), episode,
+                                                     (uint32_t)step_before, (uint32_t)b);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rw[b * 4 + i] = blk.v[i];
+            }
+        };
+        if (PRE && own_rng) gen_blocks(RAD_LATE, NBLK);
 
         // table accessors: this env's SoA column (PE) or the shared tables
         // this env's column of the per-env tables: plain SoA (row stride pe_stride) or tiled (row stride = tile width)
@@ -234,7 +295,15 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
                 double snr_f = (Pn_t > 1e-18) ? (g_D(j, target) * prj) / Pn_t : 0.0;
                 snr_f = (snr_f > 0.0) ? snr_f : 0.0;
                 const double pd_f = det_prob(snr_f, pdA, pdc1, pdden);
-                const double u = draw_uniform<FAST>(io, e, R + n_dec, (uint32_t)step_before);
+                double u;
+                if (PRE && own_rng) {
+                    uint32_t w = rw[NR];
+#pragma unroll
+                    for (int k = 1; k < NJ; ++k) w = (n_dec == k) ? rw[NR + k] : w;
+                    u = u32_mid(w);
+                } else {
+                    u = draw_uniform<FAST>(io, e, episode, R + n_dec, (uint32_t)step_before);
+                }
                 ++n_dec;
                 if (u <= pd_f) {
                     const double safe = pd_f < 0.999999 ? pd_f : 0.999999;  // environment.py:446
@@ -246,6 +315,7 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
         }
 
         // ---- detections, FSM, r_d, r_j(suppression); environment.py:316-398 ----
+        if (PRE && own_rng) gen_blocks(0, RAD_LATE);
         double r_d = 0.0, r_j = 0.0, r_j_dec = 0.0;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -254,7 +324,7 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
             const double den = t_D(r) * supp[r] + Pn;                       // :331
             const double snr_with = (den > 1e-18) ? t_GaPs(r) / den : 0.0;  // :332
             const double pd = det_prob(snr_with, pdA, pdc1, pdden);           // :337
-            const double u = draw_uniform<FAST>(io, e, r, (uint32_t)step_before);
+            const double u = (PRE && own_rng) ? u32_mid(rw[r]) : draw_uniform<FAST>(io, e, episode, r, (uint32_t)step_before);
             const bool detected = (u <= pd);                                   // :341
             // radar.py:102-117: SEARCH & detected -> TRACK, SEARCH & !detected -> SEARCH,
             // TRACK & !detected -> SEARCH, TRACK & detected -> TRACK.  The next state therefore
@@ -296,6 +366,16 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
             io.out64[e * 4 + 2] = r_p;
             io.out64[e * 4 + 3] = r_j;
         }
+    };
+    if constexpr (FAST) {
+        // one env per lane, no grid-stride loop: inside a loop every argument and table constant is loop-invariant,
+        // gets hoisted and stays live for the whole body (SGPR spills); straight-line code loads them where used
+        const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (e < io.n_envs) env_step_one(e);
+    } else {
+        for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < io.n_envs;
+             e += (int64_t)gridDim.x * blockDim.x)
+            env_step_one(e);
     }
 }
 
@@ -335,7 +415,14 @@ __global__ void __launch_bounds__(64 * (NJW + NRW)) env_step_slots_kernel(const 
     const double pdA = tb->pd_A, pdc1 = tb->pd_c1, pdden = tb->pd_denB;
     const bool arith32 = (io.P32 != nullptr) && !(io.flags & MACJD_STEP_ARITH_F64);
     const int32_t step_before = io.step[e];
+    const uint32_t episode = io.episode ? (uint32_t)io.episode[e] : 0u;
     const bool jam_wave = wave < NJW;
+    // deception slots R .. R+J-1: when they all live in ONE Philox block (3j/4r: slots 4..6 of block 1) the jammer
+    // waves generate it in phase 1, off the post-barrier path; otherwise a block per deceiving lane in phase 2
+    constexpr bool DEC_ONE_BLOCK = (R >> 2) == ((R + J - 1) >> 2);
+    Philox4 dec_blk;
+    if (DEC_ONE_BLOCK && jam_wave && !io.u)
+        dec_blk = env_philox_block(io.seed, (uint64_t)(io.env_offset + e), episode, (uint32_t)step_before, (uint32_t)(R >> 2));
 
     // ---------------- phase 1: jammer lanes, environment.py:248-302 ----------------
     double my_prj[JPW];
@@ -346,7 +433,7 @@ __global__ void __launch_bounds__(64 * (NJW + NRW)) env_step_slots_kernel(const 
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
             const int r = (wave - NJW) + rr * NRW;
-            u_radar[rr] = (r < R) ? draw_uniform(io, e, r, (uint32_t)step_before) : 2.0;
+            u_radar[rr] = (r < R) ? draw_uniform(io, e, episode, r, (uint32_t)step_before) : 2.0;
         }
     }
     if (jam_wave) {
@@ -419,7 +506,8 @@ __global__ void __launch_bounds__(64 * (NJW + NRW)) env_step_slots_kernel(const 
                     double snr_f = (Pn_t > 1e-18) ? (tb->D[target] * my_prj[jj]) / Pn_t : 0.0;
                     snr_f = (snr_f > 0.0) ? snr_f : 0.0;
                     const double pd_f = det_prob(snr_f, pdA, pdc1, pdden);
-                    const double u = draw_uniform(io, e, R + k, (uint32_t)step_before);
+                    const double u = (DEC_ONE_BLOCK && !io.u) ? u32_mid(philox_word(dec_blk, (R + k) & 3))
+                                                              : draw_uniform(io, e, episode, R + k, (uint32_t)step_before);
                     if (u <= pd_f) hitfac = 1.0 - (pd_f < 0.999999 ? pd_f : 0.999999);
                 }
                 s_hitfac[j][lane] = hitfac;
@@ -516,12 +604,13 @@ __global__ void __launch_bounds__(64 * (NJW + NRW)) env_step_slots_kernel(const 
 }
 
 __global__ void env_reset_kernel(int64_t n_envs, int R, uint8_t* track, int64_t k_se, int64_t k_sx, int32_t* step,
-                                 const uint8_t* mask) {
+                                 const uint8_t* mask, int32_t* episode) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_envs;
          e += (int64_t)gridDim.x * blockDim.x) {
         if (mask && !mask[e]) continue;
         for (int r = 0; r < R; ++r) track[e * k_se + (int64_t)r * k_sx] = 0;  // radar.py:10 initial_state SEARCH
         step[e] = 0;                                                         // environment.py:203
+        if (episode) episode[e] += 1;   // a new episode draws fresh Monte-Carlo values (environment.py:341,430)
     }
 }
 
@@ -598,14 +687,14 @@ int macjd_scenario_dims(const macjd_scenario* s, int32_t* n_radars, int32_t* n_j
 }
 
 int macjd_env_reset(const macjd_scenario* s, int64_t n_envs, uint8_t* track, int64_t k_se, int64_t k_sx,
-                    int32_t* step, const uint8_t* mask, void* hip_stream) {
+                    int32_t* step, const uint8_t* mask, int32_t* episode, void* hip_stream) {
     if (!s || !track || !step || n_envs < 0) return set_err(MACJD_EINVAL, "macjd_env_reset: bad argument");
     if (n_envs == 0) return MACJD_OK;
     const int block = 256;
     int64_t grid = (n_envs + block - 1) / block;
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(macjd::env_reset_kernel, dim3((unsigned)grid), dim3(block), 0, (hipStream_t)hip_stream, n_envs,
-                       s->host.R, track, k_se, k_sx, step, mask);
+                       s->host.R, track, k_se, k_sx, step, mask, episode);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_env_reset launch: %s", hipGetErrorString(err));
     return MACJD_OK;
@@ -651,26 +740,46 @@ static int launch_step(const macjd_scenario* s, const macjd_step_io* io, hipStre
         // large batches: 256-lane workgroups, grid-stride, tables staged once per workgroup.
         const int block = (E >= (1 << 16)) ? 256 : 64;
         int64_t grid = (E + block - 1) / block;
+        const dim3 gf((unsigned)grid), b(block);   // production variants: one env per lane, no grid-stride loop
         const int64_t cap = (block == 256) ? 256 * 8 : 256 * 16;
         if (grid > cap) grid = cap;
-        const dim3 g((unsigned)grid), b(block);
-        // production configuration (Philox uniforms, float32 actions / power arithmetic, no float64 diagnostics)
+        const dim3 g((unsigned)grid);
+        // production configuration (Philox uniforms, float32 actions / power arithmetic, no float64 diagnostics,
+        // strides that fit int32)
+        auto fits = [](int64_t v) { return v >= INT32_MIN && v <= INT32_MAX; };
         const bool fast = !io->u && io->P32 && !(io->flags & MACJD_STEP_ARITH_F64) && !io->out64 && !io->pd64 &&
-                          !io->snr64 && !io->prj64;
+                          !io->snr64 && !io->prj64 && (E + block - 1) / block <= 0x7fffffff && fits(io->T_se) &&
+                          fits(io->T_sx) && fits(io->P_se) && fits(io->P_sx) && fits(io->k_se) && fits(io->k_sx) &&
+                          fits(io->pd_se) && fits(io->pd_sx) && fits(io->sw_se) && fits(io->sw_sx);
+        macjd::FastStepIO f{};
+        if (fast) {
+            f.n_envs = io->n_envs; f.env_offset = io->env_offset; f.seed = io->seed;
+            f.T = io->T; f.P32 = io->P32; f.episode = io->episode; f.track = io->track; f.step = io->step;
+            f.reward = io->reward; f.r_dpj = io->r_dpj; f.terminated = io->terminated; f.pd = io->pd;
+            f.snr_with = io->snr_with; f.r_dpj_sum = io->r_dpj_sum; f.pe_tables = io->pe_tables;
+            f.pe_flags = io->pe_flags; f.pe_stride = io->pe_stride; f.pe_tile = io->pe_tile;
+            f.T_se = (int32_t)io->T_se; f.T_sx = (int32_t)io->T_sx; f.P_se = (int32_t)io->P_se; f.P_sx = (int32_t)io->P_sx;
+            f.k_se = (int32_t)io->k_se; f.k_sx = (int32_t)io->k_sx; f.pd_se = (int32_t)io->pd_se; f.pd_sx = (int32_t)io->pd_sx;
+            f.sw_se = (int32_t)io->sw_se; f.sw_sx = (int32_t)io->sw_sx;
+        }
 #define MACJD_LAUNCH(JT, RT)                                                                                          \
     do {                                                                                                              \
-        if (per_env && fast) hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT, true, true>), g, b, 0, stream, s->dev, *io);       \
-        else if (per_env) hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT, true, false>), g, b, 0, stream, s->dev, *io);         \
-        else if (fast) hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT, false, true>), g, b, 0, stream, s->dev, *io);            \
-        else hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT, false, false>), g, b, 0, stream, s->dev, *io);                     \
+        if (per_env && fast)                                                                                          \
+            hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT, true, true, macjd::FastStepIO>), gf, b, 0, stream, s->dev, f);      \
+        else if (per_env)                                                                                             \
+            hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT, true, false, macjd_step_io>), g, b, 0, stream, s->dev, *io);        \
+        else if (fast)                                                                                                \
+            hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT, false, true, macjd::FastStepIO>), gf, b, 0, stream, s->dev, f);     \
+        else                                                                                                          \
+            hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT, false, false, macjd_step_io>), g, b, 0, stream, s->dev, *io);       \
     } while (0)
         if (J == 3 && R == 4) MACJD_LAUNCH(3, 4);
         else if (J == 6 && R == 8) MACJD_LAUNCH(6, 8);
         else if (J == 12 && R == 16) MACJD_LAUNCH(12, 16);
         else if (J == 2 && R == 2) MACJD_LAUNCH(2, 2);
         else {   // generic sizes: one (non-FAST) variant per table mode
-            if (per_env) hipLaunchKernelGGL((macjd::env_step_kernel<0, 0, true, false>), g, b, 0, stream, s->dev, *io);
-            else hipLaunchKernelGGL((macjd::env_step_kernel<0, 0, false, false>), g, b, 0, stream, s->dev, *io);
+            if (per_env) hipLaunchKernelGGL((macjd::env_step_kernel<0, 0, true, false, macjd_step_io>), g, b, 0, stream, s->dev, *io);
+            else hipLaunchKernelGGL((macjd::env_step_kernel<0, 0, false, false, macjd_step_io>), g, b, 0, stream, s->dev, *io);
         }
 #undef MACJD_LAUNCH
     }

@@ -100,6 +100,10 @@ class BatchedElectromagneticEnvironment:
         dev = self.device
         self._track = torch.zeros((R, E), dtype=torch.uint8, device=dev)
         self._step = torch.zeros(E, dtype=torch.int32, device=dev)
+        # per-env episode index: advanced by every reset (in the reset kernel, so replayed HIP graphs advance it too)
+        # and part of the in-kernel Philox counter — each episode draws fresh Monte-Carlo values like the reference's
+        # np.random stream does (environment.py:341,430)
+        self._episode = torch.zeros(E, dtype=torch.int32, device=dev)
         self._reward = torch.zeros(E, dtype=torch.float32, device=dev)
         self._r_dpj = torch.zeros((E, 3), dtype=torch.float32, device=dev)
         self._terminated = torch.zeros(E, dtype=torch.uint8, device=dev)
@@ -159,6 +163,11 @@ class BatchedElectromagneticEnvironment:
     def step_count(self) -> torch.Tensor:
         return self._step
 
+    @property
+    def episode_index(self) -> torch.Tensor:
+        """int32 [E]: number of resets each env has seen (keys the in-kernel Monte-Carlo stream)."""
+        return self._episode
+
     def reset(self, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """All (or the masked) envs back to SEARCH / step 0 (environment.py:208-219).  Returns the
         [E, S] state view."""
@@ -169,7 +178,8 @@ class BatchedElectromagneticEnvironment:
             mptr = mask.data_ptr()
         with torch.cuda.device(self.device):
             _native.check(self._lib.macjd_env_reset(self._handle.ptr, self.batch_envs, self._track.data_ptr(),
-                                                    1, self.batch_envs, self._step.data_ptr(), mptr, stream),
+                                                    1, self.batch_envs, self._step.data_ptr(), mptr,
+                                                    self._episode.data_ptr(), stream),
                           "macjd_env_reset")
         return self.get_state()
 
@@ -205,6 +215,7 @@ class BatchedElectromagneticEnvironment:
             io.u, io.u_se, io.u_sx = u.data_ptr(), u.stride(0), u.stride(1)
         else:
             io.u, io.u_se, io.u_sx = None, 0, 0
+        io.episode = self._episode.data_ptr()
         io.track, io.k_se, io.k_sx = self._track.data_ptr(), 1, E
         io.step = self._step.data_ptr()
         rew = self._reward if reward is None else reward

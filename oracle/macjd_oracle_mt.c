@@ -23,6 +23,7 @@ static macjd_step_io slice(const macjd_scenario_desc* d, const macjd_step_io* io
     if (s.P32) s.P32 += lo * io->P_se;
     if (s.P64) s.P64 += lo * io->P_se;
     if (s.u) s.u += lo * io->u_se;
+    if (s.episode) s.episode += lo;
     s.track += lo * io->k_se;
     s.step += lo;
     if (s.reward) s.reward += lo;

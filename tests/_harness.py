@@ -23,6 +23,7 @@ class StepIO(ctypes.Structure):
         ("T", ctypes.c_void_p), ("T_se", ctypes.c_int64), ("T_sx", ctypes.c_int64),
         ("P32", ctypes.c_void_p), ("P64", ctypes.c_void_p), ("P_se", ctypes.c_int64), ("P_sx", ctypes.c_int64),
         ("u", ctypes.c_void_p), ("u_se", ctypes.c_int64), ("u_sx", ctypes.c_int64),
+        ("episode", ctypes.c_void_p),
         ("track", ctypes.c_void_p), ("k_se", ctypes.c_int64), ("k_sx", ctypes.c_int64),
         ("step", ctypes.c_void_p),
         ("reward", ctypes.c_void_p), ("r_dpj", ctypes.c_void_p), ("terminated", ctypes.c_void_p),
@@ -57,7 +58,7 @@ def oracle_lib():
         lib.macjd_oracle_env_step_mt.restype = ctypes.c_int
         lib.macjd_oracle_env_step_mt.argtypes = [ctypes.c_void_p, ctypes.POINTER(StepIO), ctypes.c_int]
         lib.macjd_oracle_uniform.restype = ctypes.c_double
-        lib.macjd_oracle_uniform.argtypes = [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
+        lib.macjd_oracle_uniform.argtypes = [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
         lib.macjd_oracle_detection_probability.restype = ctypes.c_double
         lib.macjd_oracle_detection_probability.argtypes = [ctypes.c_void_p, ctypes.c_double]
         lib.macjd_oracle_max_threads.restype = ctypes.c_int
@@ -84,11 +85,14 @@ class OracleEnv:
         self.desc, self._keep = scenario.c_desc()
         self.track = np.zeros((self.E, self.R), dtype=np.uint8)
         self.step_count = np.zeros(self.E, dtype=np.int32)
+        self.episode = np.zeros(self.E, dtype=np.int32)   # Philox episode index, advanced by reset() like the HIP env's
         self.n_threads = n_threads
 
-    def reset(self):
-        self.track[:] = 0
-        self.step_count[:] = 0
+    def reset(self, mask=None):
+        sel = slice(None) if mask is None else np.asarray(mask, dtype=bool)
+        self.track[sel] = 0
+        self.step_count[sel] = 0
+        self.episode[sel] += 1
 
     def step(self, T, P, u=None, seed=0, env_offset=0, arith_f64=False):
         """T int32[E,J]; P float32 or float64 [E,J]; u float64[E,R+J] or None (Philox)."""
@@ -115,6 +119,7 @@ class OracleEnv:
         if u is not None:
             u = np.ascontiguousarray(u, dtype=np.float64).reshape(E, R + J)
             io.u, io.u_se, io.u_sx = u.ctypes.data, R + J, 1
+        io.episode = self.episode.ctypes.data
         io.track, io.k_se, io.k_sx = self.track.ctypes.data, R, 1
         io.step = self.step_count.ctypes.data
         io.reward, io.r_dpj, io.terminated = out["reward"].ctypes.data, out["r_dpj"].ctypes.data, out["terminated"].ctypes.data

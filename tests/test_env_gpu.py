@@ -100,7 +100,7 @@ def test_philox_mode_and_layouts(name):
     env = _env(sc, E, seed=1234, env_offset=5000)
     env2 = _env(sc, E, seed=1234, env_offset=5000)
     ora = OracleEnv(sc, E, n_threads=4)
-    env.reset(); env2.reset()
+    env.reset(); env2.reset(); ora.reset()
     rng = np.random.default_rng(3)
     diag = _diag(E, R, J)
     for t in range(6):
@@ -194,6 +194,64 @@ def test_shard_invariance_and_determinism():
         assert torch.equal(r_w, r_a) and torch.equal(i_w["radar_tracking"], i_a["radar_tracking"])
         assert torch.equal(r_w, torch.cat([r_l, r_h]))
         assert torch.equal(i_w["radar_tracking"], torch.cat([i_l["radar_tracking"], i_h["radar_tracking"]]))
+
+
+def test_every_episode_draws_fresh_monte_carlo_values():
+    """The reference consumes fresh np.random.rand() values in every episode (environment.py:341,430).  In Philox mode
+    the per-env episode index (advanced by reset, also by a masked reset and by a reset replayed from a HIP graph) is
+    part of the counter: the same env with the same actions sees different detection draws in consecutive episodes,
+    every episode matches the oracle, and the values do not depend on how the envs are sharded."""
+    sc, _ = load_scenario("3j4r")
+    R, J, E = sc.num_radars, sc.num_jammers, 1536
+    rng = np.random.default_rng(21)
+    T, P = random_actions(rng, E, J, R, with_invalid=False)
+    Td, Pd = torch.from_numpy(T).cuda(), torch.from_numpy(P).cuda()
+    whole, ora = _env(sc, E, seed=31), OracleEnv(sc, E, n_threads=4)
+    lo, hi = _env(sc, E // 2, seed=31), _env(sc, E // 2, seed=31, env_offset=E // 2)
+    tracks = []
+    for ep in range(3):
+        for e_ in (whole, lo, hi):
+            e_.reset()
+        ora.reset()
+        assert int(whole.episode_index.min()) == ep + 1 == int(whole.episode_index.max())
+        ep_tracks = []
+        for t in range(4):
+            rew, term, info = whole.step(Td, Pd)
+            o = ora.step(T, P, seed=31)
+            _cmp(o, rew, term, info)
+            r_l, _, i_l = lo.step(Td[:E // 2], Pd[:E // 2])
+            r_h, _, i_h = hi.step(Td[E // 2:], Pd[E // 2:])
+            assert torch.equal(rew, torch.cat([r_l, r_h]))
+            assert torch.equal(info["radar_tracking"], torch.cat([i_l["radar_tracking"], i_h["radar_tracking"]]))
+            ep_tracks.append(info["radar_tracking"].clone())
+        tracks.append(torch.stack(ep_tracks))
+    # identical actions, different episodes: the detection outcomes differ (pd ~ 0.1: ~18 % of the flags flip)
+    for a, b in ((0, 1), (1, 2), (0, 2)):
+        frac = (tracks[a] != tracks[b]).float().mean().item()
+        assert 0.05 < frac < 0.4, frac
+    # masked reset advances only the masked envs; a reset replayed from a HIP graph advances the counter as well
+    mask = torch.zeros(E, dtype=torch.bool, device="cuda")
+    mask[::2] = True
+    whole.reset(mask)
+    ora.reset(mask.cpu().numpy())
+    assert whole.episode_index.cpu().tolist() == ora.episode.tolist()
+    _cmp(ora.step(T, P, seed=31), *whole.step(Td, Pd))
+    g = torch.cuda.CUDAGraph()
+    s_ = torch.cuda.Stream()
+    s_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s_):
+        whole.reset(); ora.reset()
+    torch.cuda.current_stream().wait_stream(s_)
+    with torch.cuda.graph(g):
+        whole.reset()
+        whole.step(Td, Pd)
+    for _ in range(2):
+        g.replay()
+        ora.reset()
+        o = ora.step(T, P, seed=31)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(whole.track.cpu().numpy(), o["track"])
+        assert whole.episode_index.cpu().tolist() == ora.episode.tolist()
 
 
 def test_reset_mask_and_outputs_into_caller_buffers():
@@ -293,6 +351,8 @@ def test_per_env_batch_equals_single_scenario_envs_and_oracle():
     env.reset()
     for s_ in singles:
         s_.reset()
+    for o_ in oracles:
+        o_.reset()
     rng = np.random.default_rng(5)
     diag = _diag(E, R, J)
     for t in range(6):

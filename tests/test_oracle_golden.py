@@ -122,12 +122,48 @@ def test_philox_known_answers():
 
 def test_philox_uniform_range_and_determinism():
     lib = oracle_lib()
-    vals = [lib.macjd_oracle_uniform(7, e, s, k) for e in range(50) for s in range(3) for k in range(7)]
+    vals = [lib.macjd_oracle_uniform(7, e, ep, s, k) for e in range(50) for ep in range(2) for s in range(3) for k in range(7)]
     a = np.array(vals)
-    assert (a >= 0).all() and (a < 1).all()
-    assert len(np.unique(a)) == a.size
-    assert lib.macjd_oracle_uniform(7, 3, 1, 2) == lib.macjd_oracle_uniform(7, 3, 1, 2)
+    assert (a > 0).all() and (a < 1).all()
+    assert len(np.unique(a)) == a.size          # every (env, episode, step, slot) has its own value
+    assert lib.macjd_oracle_uniform(7, 3, 0, 1, 2) == lib.macjd_oracle_uniform(7, 3, 0, 1, 2)
     assert abs(a.mean() - 0.5) < 0.05
+    # u = (word + 0.5) * 2^-32 of Philox block slot >> 2 (include/macjd.h): check against the raw block
+    import ctypes
+    c = (ctypes.c_uint32 * 4)(9, 4, 17, 1)      # env 9, episode 4, step 17, block 1 (slots 4..7)
+    k = (ctypes.c_uint32 * 2)(7, 0)
+    o = (ctypes.c_uint32 * 4)()
+    lib.macjd_oracle_philox4x32_10(c, k, o)
+    for w in range(4):
+        assert lib.macjd_oracle_uniform(7, 9, 4, 17, 4 + w) == (o[w] + 0.5) / 4294967296.0
+
+
+def test_oracle_episodes_draw_fresh_values_and_are_shard_invariant():
+    """Philox mode: consecutive episodes of the same env with identical actions see different detection draws
+    (the reference draws fresh np.random.rand() values every episode, environment.py:341,430); an env's values do
+    not depend on which shard it lives in."""
+    sc, _ = load_scenario("3j4r")
+    rng = np.random.default_rng(4)
+    E = 600
+    T = rng.integers(0, 2 * sc.num_radars + 1, size=(E, sc.num_jammers)).astype(np.int32)
+    P = rng.random((E, sc.num_jammers)).astype(np.float32)
+    whole, lo, hi = OracleEnv(sc, E), OracleEnv(sc, E // 2), OracleEnv(sc, E // 2)
+    per_ep = []
+    for ep in range(3):
+        for env in (whole, lo, hi):
+            env.reset()
+        tr = []
+        for t in range(3):
+            o = whole.step(T, P, seed=5)
+            ol = lo.step(T[:E // 2], P[:E // 2], seed=5)
+            oh = hi.step(T[E // 2:], P[E // 2:], seed=5, env_offset=E // 2)
+            np.testing.assert_array_equal(o["track"], np.concatenate([ol["track"], oh["track"]]))
+            np.testing.assert_array_equal(o["out64"], np.concatenate([ol["out64"], oh["out64"]]))
+            tr.append(o["track"])
+        per_ep.append(np.stack(tr))
+    for a, b in ((0, 1), (1, 2)):
+        frac = (per_ep[a] != per_ep[b]).mean()
+        assert 0.05 < frac < 0.4, frac
 
 
 def test_pd_floor_known_answer():
