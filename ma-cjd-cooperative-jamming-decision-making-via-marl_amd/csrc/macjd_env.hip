@@ -25,6 +25,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <type_traits>
 
 #include "../../include/macjd.h"
 #include "macjd_err.h"
@@ -51,26 +52,78 @@ int set_err(int code, const char* fmt, const char* a) {
     return code;
 }
 
-// core/radar.py:67-82, constants precomputed on the host (A, c1, denB)
-__device__ __forceinline__ double det_prob(double snr, double A, double c1, double denB) {
-    const double s = (0.0 > snr) ? 0.0 : snr;  // Python max(snr, 0.0)
-    const double Z = s + c1;
-    const double B = (10.0 * Z - A) / denB;
-    double p = 1.0 / (1.0 + exp(-B));
-    p = (B > 700.0) ? 1.0 : p;
-    p = (B < -700.0) ? 0.0 : p;
-    return (fabs(denB) < 1e-9) ? 0.0 : p;
+// ---- detection probability, core/radar.py:67-82 (constants A, c1, denB precomputed on the host) -------------------
+// The two divisions of the formula are done with the hardware's own IEEE division algorithm MINUS its scaling /
+// special-case wrapper (v_div_scale x2, v_div_fmas' scale step, v_div_fixup): refined reciprocal r of the divisor (v_rcp +
+// two Newton steps), q = n r, q + r (n - d q).  That is bit-for-bit what `/` compiles to whenever no operand scaling
+// is needed, which holds here by construction: the divisor of B is the scenario constant denB (|denB| >= 1e-9, else
+// the function returns 0 like the reference), its numerator is bounded through Z <= 1e300 (any Z that large gives
+// B > 700 -> pd = 1 either way); the divisor of 1 / (1 + exp(-B)) lies in [1, e^709] and every result computed from
+// B outside [-700, 700] is replaced by the reference's own saturation values.  Both refined reciprocals of a constant
+// divisor are shared by all the evaluations of an env-step (3 instead of 11 instructions per division).
+struct PdConsts {
+    double A, c1, denB, r_denB;
+    bool degenerate;   // |denB| < 1e-9 -> pd = 0 (radar.py:75-76)
+};
+__device__ __forceinline__ double rcp_refined(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ double div_by_refined(double n, double d, double r) {
+    const double q = n * r;
+    return __builtin_fma(__builtin_fma(-d, q, n), r, q);
+}
+__device__ __forceinline__ PdConsts pd_consts(double A, double c1, double denB) {
+    PdConsts k;
+    k.A = A; k.c1 = c1; k.denB = denB;
+    k.degenerate = fabs(denB) < 1e-9;
+    k.r_denB = rcp_refined(k.degenerate ? 1.0 : denB);
+    return k;
+}
+// N independent evaluations side by side: straight-line code, the exp polynomial's constants are materialised once
+// and the N dependency chains interleave (the one-at-a-time form spent ~150 v_mov on constants per env-step and ran
+// each chain alone)
+template <int N>
+__device__ __forceinline__ void det_prob_batch(const double* snr, double* pd, const PdConsts& k) {
+    double B[N], den[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double s = (0.0 > snr[i]) ? 0.0 : snr[i];  // Python max(snr, 0.0)
+        double Z = s + k.c1;
+        Z = (Z < 1e300) ? Z : 1e300;
+        B[i] = div_by_refined(10.0 * Z - k.A, k.denB, k.r_denB);
+        den[i] = 1.0 + exp(-B[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double r = rcp_refined(den[i]);
+        double p = div_by_refined(1.0, den[i], r);
+        p = (B[i] > 700.0) ? 1.0 : p;
+        p = (B[i] < -700.0) ? 0.0 : p;
+        pd[i] = k.degenerate ? 0.0 : p;
+    }
+}
+__device__ __forceinline__ double det_prob(double snr, const PdConsts& k) {
+    double p;
+    det_prob_batch<1>(&snr, &p, k);
+    return p;
 }
 
 // Uniform of (env e, slot) for the step that starts at `step_before` (include/macjd.h, macjd_step_io.u): supplied by the
 // caller, or word (slot & 3) of the env's Philox block (slot >> 2).  This on-demand form generates a whole block per
 // call; the kernels below generate each block they need ONCE per env-step and pick words out of it.
+// Word w (0..3, possibly different per lane) of a block, as shifts on 64-bit pairs.  NOT b.v[w] and not a chain of
+// selects on w either: hipcc turns both into a dynamically indexed private array, promotes that array to LDS and, to
+// find its slice of it, reads the workgroup size from the dispatch packet — an uncached load from the AQL queue that
+// cost the slot kernel 5 - 10 us per launch (3.9 -> 13.6 us at E = 4096; `.amdhsa_user_sgpr_dispatch_ptr 1` in the
+// kernel descriptor is the tell-tale).
 __device__ __forceinline__ uint32_t philox_word(const Philox4& b, int w) {
-    uint32_t x = b.v[0];
-    x = (w == 1) ? b.v[1] : x;
-    x = (w == 2) ? b.v[2] : x;
-    x = (w == 3) ? b.v[3] : x;
-    return x;
+    const uint64_t lo = ((uint64_t)b.v[1] << 32) | b.v[0], hi = ((uint64_t)b.v[3] << 32) | b.v[2];
+    const uint64_t pair = (w & 2) ? hi : lo;
+    return (uint32_t)(pair >> ((w & 1) * 32));
 }
 template <bool PHILOX_ONLY = false, class IO = macjd_step_io>
 __device__ __forceinline__ double draw_uniform(const IO& io, int64_t e, uint32_t episode, int slot,
@@ -145,22 +198,33 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
     }
 
     const double rp_min = tb->rp_min, rp_max = tb->rp_max;
-    const double pdA = tb->pd_A, pdc1 = tb->pd_c1, pdden = tb->pd_denB;
+    const PdConsts pdk = pd_consts(tb->pd_A, tb->pd_c1, tb->pd_denB);
     const int32_t episode_limit = tb->episode_limit;
     const bool arith32 = FAST ? true : ((io.P32 != nullptr) && !(io.flags & MACJD_STEP_ARITH_F64));
 
     auto env_step_one = [&](const int64_t e) {
-        const int32_t step_before = io.step[e];
+        // Element (env e, item k) of a caller-strided array.  Production variant: the BYTE offset is formed in 32 bits
+        // (the host checks that every offset of the launch fits) and added to the wave-uniform base pointer, which is
+        // the SGPR-base + 32-bit-VGPR-offset addressing form of global_load / global_store — no 64-bit VALU address
+        // arithmetic per access (~50 instructions per env-step at 3j/4r).
+        auto at = [&](auto* base, auto se, int k, auto sx) -> decltype(*base)& {
+            using T_ = std::remove_reference_t<decltype(*base)>;
+            if constexpr (FAST) {
+                const uint32_t off = ((uint32_t)e * (uint32_t)se + (uint32_t)k * (uint32_t)sx) * (uint32_t)sizeof(T_);
+                using C_ = std::conditional_t<std::is_const_v<T_>, const char, char>;
+                return *reinterpret_cast<T_*>(reinterpret_cast<C_*>(base) + off);
+            } else {
+                return base[e * (int64_t)se + (int64_t)k * (int64_t)sx];
+            }
+        };
+        const int32_t step_before = at(io.step, 1, 0, 0);
         const int32_t step_count = step_before + 1;  // environment.py:235
-        const uint32_t episode = io.episode ? (uint32_t)io.episode[e] : 0u;
+        const uint32_t episode = io.episode ? (uint32_t)at(io.episode, 1, 0, 0) : 0u;
         // Monte-Carlo uniforms of this env-step (R radar slots, then one per valid deception action): every Philox
-        // block is generated once (ceil((R + J) / 4) blocks: 2 at 3j/4r) — the blocks holding deception slots before
-        // the jammer loop (a deception action selects word R + n_dec), the radar-only blocks after it, where the
-        // radar loop reads its words at compile-time indices (8 fewer live VGPRs across the jammer loop).
+        // block is generated once (ceil((R + J) / 4) blocks: 2 at 3j/4r); the radar pass reads its words at
+        // compile-time indices, a deception action selects word R + n_dec.
         constexpr bool PRE = JT && RT;   // generic sizes generate a block on demand instead
         constexpr int NBLK = PRE ? (NJ + NR + 3) / 4 : 1;
-        constexpr int DEC_B0 = NR >> 2;                       // first block with a deception slot
-        constexpr int RAD_LATE = PRE ? DEC_B0 : 0;            // blocks [0, RAD_LATE) hold radar slots only
         uint32_t rw[NBLK * 4];
         const bool own_rng = FAST || !io.u;
         auto gen_blocks = [&](const int b0, const int b1) {
@@ -172,7 +236,7 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
                 for (int i = 0; i < 4; ++i) rw[b * 4 + i] = blk.v[i];
             }
         };
-        if (PRE && own_rng) gen_blocks(RAD_LATE, NBLK);
+        if (PRE && own_rng) gen_blocks(0, NBLK);
 
         // table accessors: this env's SoA column (PE) or the shared tables
         // this env's column of the per-env tables: plain SoA (row stride pe_stride) or tiled (row stride = tile width)
@@ -200,7 +264,7 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
                 for (int j = 0; j < NJ; ++j) pv_j[k * NJ + j] = pe[(int64_t)(6 * R + k * J + j) * ps];   // pmin, pmax, gj
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int32_t Tj = io.T[e * io.T_se + (int64_t)j * io.T_sx];
+                const int32_t Tj = at(io.T, io.T_se, j, io.T_sx);
                 const int tj = ((Tj >= 1) && (Tj <= 2 * R)) ? ((Tj + 1) / 2 - 1) : 0;
                 gv_denom[j] = pe[(int64_t)(6 * R + 3 * J + j * R + tj) * ps];
                 gv_gr[j] = pe[(int64_t)(5 * R + tj) * ps];
@@ -228,6 +292,12 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
             return HOIST ? gv_fl[j] : PE ? pf[(int64_t)(j * R + t) * ps] : s_flags[j * R + t];
         };
 
+        // The step runs as straight-line passes over the (compile-time unrolled) jammers and radars: (1) decode, power,
+        // received power, suppression sums; (2) SNR per radar; (3) ALL R + J detection probabilities side by side
+        // (det_prob_batch); (4) the deception draws in jammer order; (5) detection draws, FSM, reward terms in radar
+        // order.  Same arithmetic, operation order and RNG slots as the reference's interleaved loops; the deception
+        // quantities of a jammer that is not deceiving are computed on zeros and never used.
+        constexpr int NP = PRE ? NR + NJ : 1;
         double supp[NR];   // environment.py:241
         double prod[NR];   // environment.py:443-447
 #pragma unroll
@@ -236,12 +306,14 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
         uint32_t hit_mask = 0;   // radars with >= 1 detected false target
         int n_dec = 0;           // valid deception actions so far (RNG slot R + k)
         double r_p = 0.0;        // environment.py:371-378
+        double snr_all[NP], pd_all[NP];   // [0, NR): radars, [NR, NR + NJ): false targets of deceiving jammers
+        int dec_tgt[NJ];                  // target radar of jammer j's valid deception action, -1 = none
 
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             if (!JT && j >= J) break;
             // ---- action decode, environment.py:249-268 ----
-            const int32_t T = io.T[e * io.T_se + (int64_t)j * io.T_sx];
+            const int32_t T = at(io.T, io.T_se, j, io.T_sx);
             const bool is_jamming = (T >= 1) && (T <= 2 * R);
             const int target = is_jamming ? ((T + 1) / 2 - 1) : 0;
             const int jtype = T % 2;  // 1 = suppression, 0 = deception (only read when is_jamming)
@@ -252,14 +324,14 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
             double actual_d, norm;
             float actual_f = 0.0f;
             if (arith32) {
-                float Pc = io.P32[e * io.P_se + (int64_t)j * io.P_sx];
+                float Pc = at(io.P32, io.P_se, j, io.P_sx);
                 Pc = Pc < 0.0f ? 0.0f : (Pc > 1.0f ? 1.0f : Pc);  // np.clip, NaN propagates
                 actual_f = (float)pmin + Pc * (float)power_range;
                 actual_d = (double)actual_f;
                 norm = (power_range > 1e-6) ? (double)((actual_f - (float)pmin) / (float)power_range) : 0.0;
             } else {
                 double Pc = io.P64 ? io.P64[e * io.P_se + (int64_t)j * io.P_sx]
-                                   : (double)io.P32[e * io.P_se + (int64_t)j * io.P_sx];
+                                   : (double)at(io.P32, io.P_se, j, io.P_sx);
                 Pc = Pc < 0.0 ? 0.0 : (Pc > 1.0 ? 1.0 : Pc);
                 actual_d = pmin + Pc * power_range;
                 norm = (power_range > 1e-6) ? (actual_d - pmin) / power_range : 0.0;
@@ -270,7 +342,20 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
             const double denom = g_denom(j, target);
             const bool recorded = is_jamming && (actual_d > 0.0) && (denom >= 0.0);
             double prj = 0.0;
-            if (recorded && denom > 1e-18) {
+            if (PRE) {
+                // branch-free: the quotient is evaluated on a harmless divisor where the reference does not divide
+                const bool live = recorded && denom > 1e-18;
+                const double dsafe = live ? denom : 1.0;
+                const double grj = g_gr(j, target);
+                double q;
+                if (arith32) {
+                    const float num = (actual_f * (float)t_gj(j)) * (float)grj;
+                    q = (g_flags(j, target) & MACJD_JR_WEAK_DENOM) ? (double)(num / (float)dsafe) : (double)num / dsafe;
+                } else {
+                    q = (actual_d * t_gj(j) * grj) / dsafe;
+                }
+                prj = (live && q > 0.0) ? q : 0.0;  // Python max(0.0, x)
+            } else if (recorded && denom > 1e-18) {
                 const double grj = g_gr(j, target);
                 if (arith32) {
                     const float num = (actual_f * (float)t_gj(j)) * (float)grj;
@@ -287,23 +372,23 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
             const bool is_dec = recorded && (jtype == 0);
             supp_mask |= is_sup ? (1u << target) : 0u;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) supp[r] += (is_sup && target == r) ? prj : 0.0;  // environment.py:299
+            for (int r = 0; r < NR; ++r)   // environment.py:299; fma(prj, 1 or 0, supp) == supp + prj or supp, bit for bit
+                supp[r] = PRE ? __builtin_fma(prj, (is_sup && target == r) ? 1.0 : 0.0, supp[r])
+                              : supp[r] + ((is_sup && target == r) ? prj : 0.0);
+            dec_tgt[j] = is_dec ? target : -1;
 
-            // ---- deception: false-target detection, environment.py:410-434 ----
-            if (is_dec) {
+            // ---- deception: SNR of the false target, environment.py:410-422 ----
+            if (PRE) {
+                const double Pn_t = g_Pn(j, target);
+                const bool live = is_dec && Pn_t > 1e-18;
+                const double snr_f = (g_D(j, target) * prj) / (live ? Pn_t : 1.0);
+                snr_all[NR + j] = (live && snr_f > 0.0) ? snr_f : 0.0;
+            } else if (is_dec) {   // generic sizes: one evaluation at a time, only where needed
                 const double Pn_t = g_Pn(j, target);
                 double snr_f = (Pn_t > 1e-18) ? (g_D(j, target) * prj) / Pn_t : 0.0;
                 snr_f = (snr_f > 0.0) ? snr_f : 0.0;
-                const double pd_f = det_prob(snr_f, pdA, pdc1, pdden);
-                double u;
-                if (PRE && own_rng) {
-                    uint32_t w = rw[NR];
-#pragma unroll
-                    for (int k = 1; k < NJ; ++k) w = (n_dec == k) ? rw[NR + k] : w;
-                    u = u32_mid(w);
-                } else {
-                    u = draw_uniform<FAST>(io, e, episode, R + n_dec, (uint32_t)step_before);
-                }
+                const double pd_f = det_prob(snr_f, pdk);
+                const double u = draw_uniform<FAST>(io, e, episode, R + n_dec, (uint32_t)step_before);
                 ++n_dec;
                 if (u <= pd_f) {
                     const double safe = pd_f < 0.999999 ? pd_f : 0.999999;  // environment.py:446
@@ -314,16 +399,56 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
             }
         }
 
-        // ---- detections, FSM, r_d, r_j(suppression); environment.py:316-398 ----
-        if (PRE && own_rng) gen_blocks(0, RAD_LATE);
-        double r_d = 0.0, r_j = 0.0, r_j_dec = 0.0;
+        // ---- SNR with jamming, environment.py:316-333 ----
+        double snr_w[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             if (!RT && r >= R) break;
             const double Pn = t_Pn(r);
             const double den = t_D(r) * supp[r] + Pn;                       // :331
-            const double snr_with = (den > 1e-18) ? t_GaPs(r) / den : 0.0;  // :332
-            const double pd = det_prob(snr_with, pdA, pdc1, pdden);           // :337
+            if (PRE) {
+                const bool live = den > 1e-18;
+                const double q = t_GaPs(r) / (live ? den : 1.0);
+                snr_w[r] = live ? q : 0.0;                                   // :332
+                snr_all[r] = snr_w[r];
+            } else {
+                snr_w[r] = (den > 1e-18) ? t_GaPs(r) / den : 0.0;            // :332
+            }
+        }
+        if (PRE) det_prob_batch<NP>(snr_all, pd_all, pdk);                   // :337, :425
+
+        // ---- deception: Monte-Carlo detection of the false targets in jammer order, environment.py:425-447 ----
+        if (PRE) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const bool is_dec = dec_tgt[j] >= 0;
+                double u;
+                if (own_rng) {
+                    uint32_t w = rw[NR];
+#pragma unroll
+                    for (int k = 1; k < NJ; ++k) w = (n_dec == k) ? rw[NR + k] : w;
+                    u = u32_mid(w);
+                } else {
+                    u = is_dec ? io.u[e * io.u_se + (int64_t)(R + n_dec) * io.u_sx] : 2.0;
+                }
+                n_dec += is_dec ? 1 : 0;
+                const double pd_f = pd_all[NR + j];
+                const bool hit = is_dec && (u <= pd_f);                      // :430-434
+                const double safe = pd_f < 0.999999 ? pd_f : 0.999999;      // :446
+                hit_mask |= hit ? (1u << dec_tgt[j]) : 0u;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) prod[r] = (hit && dec_tgt[j] == r) ? prod[r] * (1.0 - safe) : prod[r];
+            }
+        }
+
+        // ---- detections, FSM, r_d, r_j(suppression); environment.py:337-398 ----
+        double r_d = 0.0, r_j = 0.0, r_j_dec = 0.0;
+        double pd_r[NR];
+        uint32_t track_bits = 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (!RT && r >= R) break;
+            const double pd = PRE ? pd_all[r] : det_prob(snr_w[r], pdk);    // :337
             const double u = (PRE && own_rng) ? u32_mid(rw[r]) : draw_uniform<FAST>(io, e, episode, r, (uint32_t)step_before);
             const bool detected = (u <= pd);                                   // :341
             // radar.py:102-117: SEARCH & detected -> TRACK, SEARCH & !detected -> SEARCH,
@@ -331,34 +456,39 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
             // equals `detected` whatever the previous state was, so the previous state is never
             // read (saves R bytes of HBM reads per env-step); `track` is write-only here.
             const bool tracking = detected;
-            io.track[e * io.k_se + (int64_t)r * io.k_sx] = tracking ? 1 : 0;
+            track_bits |= tracking ? (1u << r) : 0u;
             r_d += tracking ? t_rdpen(r) : 0.0;                             // :359-366 (post-update state)
-            if (supp_mask & (1u << r)) {                                       // :396-398
-                const double red = t_pdno(r) - pd;
-                r_j += (red > 0.0) ? red : 0.0;
-            }
-            if (hit_mask & (1u << r)) r_j_dec += 1.0 - prod[r];               // :438-451
-            const double snr_rep = (snr_with > 0.0) ? snr_with : 0.0;         // :333
-            if (io.pd) io.pd[e * io.pd_se + (int64_t)r * io.pd_sx] = (float)pd;
-            if (io.snr_with) io.snr_with[e * io.sw_se + (int64_t)r * io.sw_sx] = (float)snr_rep;
-            if (!FAST && io.pd64) io.pd64[e * R + r] = pd;
+            const double red = t_pdno(r) - pd;                               // :396-398
+            r_j += ((supp_mask & (1u << r)) && red > 0.0) ? red : 0.0;
+            r_j_dec += (hit_mask & (1u << r)) ? 1.0 - prod[r] : 0.0;          // :438-451
+            pd_r[r] = pd;
+        }
+        // per-radar outputs (the only conditional code of the pass: kept behind the arithmetic)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (!RT && r >= R) break;
+            const double snr_rep = (snr_w[r] > 0.0) ? snr_w[r] : 0.0;         // :333
+            at(io.track, io.k_se, r, io.k_sx) = (track_bits >> r) & 1u;
+            if (io.pd) at(io.pd, io.pd_se, r, io.pd_sx) = (float)pd_r[r];
+            if (io.snr_with) at(io.snr_with, io.sw_se, r, io.sw_sx) = (float)snr_rep;
+            if (!FAST && io.pd64) io.pd64[e * R + r] = pd_r[r];
             if (!FAST && io.snr64) io.snr64[e * R + r] = snr_rep;
         }
         r_j += r_j_dec;                          // :454
         const double reward = r_d + r_p + r_j;  // :457
 
-        io.step[e] = step_count;
-        if (io.terminated) io.terminated[e] = (step_count >= episode_limit) ? 1 : 0;  // :460
-        if (io.reward) io.reward[e] = (float)reward;
+        at(io.step, 1, 0, 0) = step_count;
+        if (io.terminated) at(io.terminated, 1, 0, 0) = (step_count >= episode_limit) ? 1 : 0;  // :460
+        if (io.reward) at(io.reward, 1, 0, 0) = (float)reward;
         if (io.r_dpj) {
-            io.r_dpj[e * 3 + 0] = (float)r_d;
-            io.r_dpj[e * 3 + 1] = (float)r_p;
-            io.r_dpj[e * 3 + 2] = (float)r_j;
+            at(io.r_dpj, 3, 0, 1) = (float)r_d;
+            at(io.r_dpj, 3, 1, 1) = (float)r_p;
+            at(io.r_dpj, 3, 2, 1) = (float)r_j;
         }
         if (io.r_dpj_sum) {
-            io.r_dpj_sum[e * 3 + 0] += (float)r_d;
-            io.r_dpj_sum[e * 3 + 1] += (float)r_p;
-            io.r_dpj_sum[e * 3 + 2] += (float)r_j;
+            at(io.r_dpj_sum, 3, 0, 1) += (float)r_d;
+            at(io.r_dpj_sum, 3, 1, 1) += (float)r_p;
+            at(io.r_dpj_sum, 3, 2, 1) += (float)r_j;
         }
         if (!FAST && io.out64) {
             io.out64[e * 4 + 0] = reward;
@@ -412,7 +542,7 @@ __global__ void __launch_bounds__(64 * (NJW + NRW)) env_step_slots_kernel(const 
     __shared__ int s_meta[J][64];  // bits 0..7 target radar, bit 8 valid suppression, bit 9 valid deception
     __shared__ double s_rd[R][64], s_rjs[R][64], s_rjd[R][64];
 
-    const double pdA = tb->pd_A, pdc1 = tb->pd_c1, pdden = tb->pd_denB;
+    const PdConsts pdk = pd_consts(tb->pd_A, tb->pd_c1, tb->pd_denB);
     const bool arith32 = (io.P32 != nullptr) && !(io.flags & MACJD_STEP_ARITH_F64);
     const int32_t step_before = io.step[e];
     const uint32_t episode = io.episode ? (uint32_t)io.episode[e] : 0u;
@@ -505,7 +635,7 @@ __global__ void __launch_bounds__(64 * (NJW + NRW)) env_step_slots_kernel(const 
                     const double Pn_t = tb->Pn[target];
                     double snr_f = (Pn_t > 1e-18) ? (tb->D[target] * my_prj[jj]) / Pn_t : 0.0;
                     snr_f = (snr_f > 0.0) ? snr_f : 0.0;
-                    const double pd_f = det_prob(snr_f, pdA, pdc1, pdden);
+                    const double pd_f = det_prob(snr_f, pdk);
                     const double u = (DEC_ONE_BLOCK && !io.u) ? u32_mid(philox_word(dec_blk, (R + k) & 3))
                                                               : draw_uniform(io, e, episode, R + k, (uint32_t)step_before);
                     if (u <= pd_f) hitfac = 1.0 - (pd_f < 0.999999 ? pd_f : 0.999999);
@@ -531,7 +661,7 @@ __global__ void __launch_bounds__(64 * (NJW + NRW)) env_step_slots_kernel(const 
                 const double Pn = tb->Pn[r];
                 const double den = tb->D[r] * supp + Pn;
                 const double snr_with = (den > 1e-18) ? tb->GaPs[r] / den : 0.0;
-                const double pd = det_prob(snr_with, pdA, pdc1, pdden);
+                const double pd = det_prob(snr_with, pdk);
                 const bool tracking = (u_radar[rr] <= pd);  // next FSM state == detected (radar.py:102-117)
                 const double red = tb->pd_no[r] - pd;
                 s_rd[r][lane] = tracking ? tb->rd_pen[r] : 0.0;
@@ -746,11 +876,16 @@ static int launch_step(const macjd_scenario* s, const macjd_step_io* io, hipStre
         const dim3 g((unsigned)grid);
         // production configuration (Philox uniforms, float32 actions / power arithmetic, no float64 diagnostics,
         // strides that fit int32)
-        auto fits = [](int64_t v) { return v >= INT32_MIN && v <= INT32_MAX; };
+        // ... and every byte offset of the launch below 2^32 (the production variant forms them in 32 bits)
+        auto span_ok = [&](int64_t se, int64_t sx, int items, int64_t elem) {
+            return se >= 0 && sx >= 0 && ((E - 1) * se + (int64_t)(items - 1) * sx + 1) * elem < (int64_t)1 << 32;
+        };
         const bool fast = !io->u && io->P32 && !(io->flags & MACJD_STEP_ARITH_F64) && !io->out64 && !io->pd64 &&
-                          !io->snr64 && !io->prj64 && (E + block - 1) / block <= 0x7fffffff && fits(io->T_se) &&
-                          fits(io->T_sx) && fits(io->P_se) && fits(io->P_sx) && fits(io->k_se) && fits(io->k_sx) &&
-                          fits(io->pd_se) && fits(io->pd_sx) && fits(io->sw_se) && fits(io->sw_sx);
+                          !io->snr64 && !io->prj64 && (E + block - 1) / block <= 0x7fffffff &&
+                          span_ok(io->T_se, io->T_sx, J, 4) && span_ok(io->P_se, io->P_sx, J, 4) &&
+                          span_ok(io->k_se, io->k_sx, R, 1) && span_ok(3, 1, 3, 4) &&
+                          (!io->pd || span_ok(io->pd_se, io->pd_sx, R, 4)) &&
+                          (!io->snr_with || span_ok(io->sw_se, io->sw_sx, R, 4));
         macjd::FastStepIO f{};
         if (fast) {
             f.n_envs = io->n_envs; f.env_offset = io->env_offset; f.seed = io->seed;
