@@ -327,7 +327,9 @@ int macjd_rowdot(const macjd_rowdot_io* io, void* hip_stream);
  * core/networks.py:100-113): given gi = W_ih x + b_ih and gh = W_hh h + b_hh ([N,3H], gate order r, z, n),
  *   r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r gh_n), h' = (h - n) z + n,
  * written to h_out and, optionally, to a second destination (the batched runner's staging row) in the same launch
- * (replaces the fused-cell launch + the copy).  H must be a multiple of 4; h_out may alias h.
+ * (replaces the fused-cell launch + the copy).  H must be a multiple of 4; h_out may alias h.  gi_ld = 0 broadcasts
+ * ONE gi row to all N rows (the observation of every env / agent is the same static vector, so its input transform
+ * is computed once per episode batch).
  */
 typedef struct macjd_grugates_io {
     int64_t n_rows;

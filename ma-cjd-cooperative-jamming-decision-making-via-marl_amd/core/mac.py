@@ -45,6 +45,33 @@ class BasicMAC:
         # optional float32 [E,J,H] destination that also receives the post-update hidden state of the NEXT
         # select_actions call (the batched runner's staging row: no separate copy launch)
         self.hidden_out = None
+        # (params_all [N, A], gi [N, 3H]) of observations that do not change during an episode, set by
+        # prepare_static_obs(); while set, select_actions skips the actor and the fc1 -> W_ih chains
+        self.static_inputs = None
+
+    def prepare_static_obs(self, obs_batch):
+        """The environment's observation is constant within an episode (the batched runner asks the env:
+        ``observation_is_static``; reference simulation/environment.py:479-522 builds it from static scenario parameters
+        only, :237-238 is a TODO): the actor output and the GRU input transform are then the same tensors at every
+        step, so they are computed here ONCE per episode batch — and for ONE row when every (env, agent) row is the
+        same vector (shared scenario: the observation is a stride-0 broadcast) — instead of at each of the
+        episode_limit steps.  ``obs_batch`` [E, J, S]; pass None to go back to per-step evaluation."""
+        if obs_batch is None:
+            self.static_inputs = None
+            return
+        device = next(self.agent.parameters()).device
+        obs = obs_batch.to(device) if obs_batch.device != device else obs_batch
+        E, J, S = obs.shape
+        with torch.no_grad():
+            if obs.stride(0) == 0 and obs.stride(1) == 0:            # one vector broadcast over envs and agents
+                p1, g1 = self.agent.static_step_inputs(obs[0, 0].reshape(1, S))
+                params, gi = p1.expand(E * J, -1), g1.expand(E * J, -1)     # stride-0 rows: no memory, no copy
+            elif obs.stride(1) == 0:                                 # one vector per env (per-env scenarios)
+                pe, ge = self.agent.static_step_inputs(obs[:, 0].reshape(E, S))
+                params, gi = pe.repeat_interleave(J, dim=0), ge.repeat_interleave(J, dim=0)
+            else:
+                params, gi = self.agent.static_step_inputs(obs.reshape(E * J, S))
+        self.static_inputs = (params, gi)
 
     def select_actions(self, obs_batch, avail_actions_batch, t_env, test_mode=False):
         device = next(self.agent.parameters()).device
@@ -57,7 +84,11 @@ class BasicMAC:
         batch_size = obs_batch.shape[0]
         obs_reshaped = obs_batch.reshape(-1, self.input_shape)
         with torch.no_grad():
-            h_new, params_all = self.forward(obs_reshaped, self.hidden_states, h_out2=self.hidden_out)
+            if self.static_inputs is not None and self.static_inputs[0].shape[0] == obs_reshaped.shape[0]:
+                params_all, gi = self.static_inputs
+                h_new = self.agent.step_from_gi(gi, self.hidden_states, h_out2=self.hidden_out)
+            else:
+                h_new, params_all = self.forward(obs_reshaped, self.hidden_states, h_out2=self.hidden_out)
             self.hidden_out = None
             self.hidden_states = h_new.detach()  # mac.py:107
             agent = self.agent

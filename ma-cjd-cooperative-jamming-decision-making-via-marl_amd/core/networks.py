@@ -118,6 +118,20 @@ class RNNAgent(nn.Module):
                 h_out2.view(h.shape).copy_(h.detach())
         return h, self.actor_forward(x)
 
+    def static_step_inputs(self, rows):
+        """(continuous params for all actions [n, A], gi = W_ih ReLU(fc1 obs) + b_ih [n, 3H]) for observation rows that
+        stay the same for a whole episode: everything of the agent step that does not depend on the hidden state
+        (networks.py:100,127).  One launch on the HIP inference path (the two chains read the same rows)."""
+        if self._fused_ok(rows) and rows.dim() == 2 and self.fused_actor and self.fused_gi_step:
+            return ops.mlp_forward_pair(rows, self.actor_layers(), rows, self.gi_layers())
+        return self.actor_forward(rows), self.gru_input_transform(rows, fused=self.fused_gi_step)
+
+    def step_from_gi(self, gi, h_in, h_out2=None):
+        """h' of one GRUCell step given the precomputed input transform gi (see static_step_inputs): the recurrent
+        GEMM + the gates launch."""
+        gh = F.linear(h_in.to(gi.device), self.rnn.weight_hh, self.rnn.bias_hh)
+        return ops.gru_gates(gi, gh, h_in, out2=h_out2)
+
     def actor_forward(self, inputs):
         """Continuous parameter for EVERY discrete action, [N, A] in (0,1)  (networks.py:116-129)."""
         if self.fused_actor and self._fused_ok(inputs):

@@ -74,6 +74,33 @@ class QMixLearner:
         self._flat_param = None
         if self.device.type == "cuda":
             self._flatten_trainable()
+        self._body_versions = None
+        self._mark_body_shared()   # target_mac is a deep copy of mac (qmix.py:53)
+
+    # ------------------------------------------------------------------ frozen agent body
+    @staticmethod
+    def _body_params(agent):
+        """fc1 / GRU / actor: the parameters the loss never reaches (module docstring)."""
+        return list(agent.fc1.parameters()) + list(agent.rnn.parameters()) + list(agent.actor.parameters())
+
+    def _mark_body_shared(self):
+        """Record that the two controllers' bodies hold identical values right now (after the deep copy in the
+        constructor and after every hard target sync).  ``_body_is_shared`` stays true until any of those tensors is
+        written again (their autograd version counters move): another optimiser training the body, a checkpoint loaded
+        into one controller only, ...  The reference's own learner never changes them (qmix.py:161-184: the loss only
+        reaches fc2_q_head and the mixer), so in reference-faithful training the eval and target unrolls share one
+        input transform, one GRU scan and one actor chain for ever."""
+        pe, pt = self._body_params(self.mac.agent), self._body_params(self.target_mac.agent)
+        self._body_versions = [(p, p._version, q, q._version) for p, q in zip(pe, pt)]
+
+    def _body_is_shared(self):
+        if os.environ.get("MACJD_SHARED_BODY", "1") == "0" or not self._body_versions:
+            return False
+        pe = self._body_params(self.mac.agent)
+        if len(pe) != len(self._body_versions):
+            return False
+        return all(p is p0 and p._version == vp and q._version == vq
+                   for p, (p0, vp, q, vq) in zip(pe, self._body_versions))
 
     # ------------------------------------------------------------------ distributed gradients
     def _trainable(self):
@@ -251,61 +278,40 @@ class QMixLearner:
         rows = st["obs"].reshape(n, -1)
         heads = [(m.agent.fc2_q_head[0].weight, m.agent.fc2_q_head[2].weight, m.agent.fc2_q_head[2].bias) for m in macs]
 
-        # Two streams inside the (captured) update, balanced by hand from the kernel timeline
-        # (scripts/timeline_update.py):
-        #   side stream   (no grad) fc1 -> W_ih of both controllers (one dense-chain pair launch) -> the fused scan
-        #                 (~55 us latency chain) -> Q-head base GEMMs -> the target controller's frozen actor chain
-        #   this stream   (no grad) the eval controller's frozen actor chain -> (autograd) Q-head on the STORED hidden
-        #                 states + eval mixer -> (no grad) the target mixer's hyper-networks (they read only the state)
-        #   ONE join, then on this stream the two Double-DQN Q-head launches, the target mixer tail and the loss.
-        # Autograd only ever sees this stream.  The split took the step from 0.565 to 0.490 ms when it was introduced.
-        # MACJD_UPDATE_LAYOUT picks where the two movable no-grad pieces run (10 interleaved bench runs each on one
-        # box, median ms / step):  0 = actor chains + target hyper-networks on this stream      0.3855
-        #                          1 = target hyper-networks behind the scan chain instead      0.3742
-        #                          2 = actor chains behind the scan chain instead (default)     0.3693
-        # re-measured once the host ran ahead of the GPU (4 runs each, +-0.3 %): 0: 0.3569, 1: 0.3696, 2: 0.3512,
-        # 3 (= 2 with the origin stream's launches captured between the scan and the rest of the side stream): 0.3514,
-        # 4 (actor chains AND target hyper-networks behind the scan chain): 0.3902 vs 0.3517 for 2.
-        # 5 (= 2 + the Double-DQN launches at the end of the side stream): 0.3514 vs 0.3519 — the side stream is the
-        # longer branch in the un-profiled run.  6 (target actor chain behind the scan chain, eval actor chain FIRST on
-        # this stream, two single launches; default): 0.3469 vs 0.3523 for 2.  7 (= 6 with this stream's actor chain
-        # issued last): 0.3570 vs 0.3463 for 6.
-        # 8 (= 6 with the target mixer's hyper-networks issued before the eval forward): 0.3644 vs 0.3607 for 6.
-        # (timeline before: side stream done at ~120 us, this stream at ~220 us; the branch a replayed graph starts
-        # second begins 30 - 50 us late whatever it holds).  Variants measured equal within noise earlier: the Q-head /
-        # tail launches on the side stream behind two events, a third stream for the actor / hyper-network work.
-        # Forks taken from a forked stream crash hipStreamEndCapture (ROCm 7.2): every fork hangs off the capture's
-        # origin stream.
-        def scan_only():
-            a0, a1 = macs[0].agent, macs[1].agent
-            if rows.is_cuda and a0.fused_gi and a1.fused_gi and not torch.is_grad_enabled():
-                # fc1 -> ReLU -> W_ih of both controllers: one launch of the dense-chain kernel
-                gis = [g.view(B, T1, J, 3 * H) for g in ops.mlp_forward_pair(rows, a0.gi_layers(), rows, a1.gi_layers())]
-            else:
-                gis = [m.agent.gru_input_transform(rows).view(B, T1, J, 3 * H) for m in macs]  # networks.py:100
-            return ops.gru_sequence_multi(gis, [m.agent.rnn.weight_hh for m in macs],
-                                          [m.agent.rnn.bias_hh for m in macs])                   # h_0 = 0, qmix.py:241
+        # Frozen agent body (fc1 / GRU / actor identical in both controllers, see _body_is_shared): ONE input transform,
+        # ONE scan and ONE actor chain serve both networks; only the Q-heads differ.
+        shared = self._body_is_shared()
+        body = macs[1].agent   # the network whose body is evaluated when shared
 
-        def bases_of(h_alls):
+        # Two streams inside the (captured) update (kernel timeline: scripts/timeline_update.py; the measured
+        # alternatives are tabulated in DESIGN.md 4.8):
+        #   side stream   (no grad) fc1 -> W_ih (dense-chain launch) -> the fused scan (~55 us latency chain) -> the
+        #                 Q-head base GEMMs [-> the target controller's actor chain when the bodies differ]
+        #   this stream   (no grad) the (eval) actor chain -> (autograd) Q-head on the STORED hidden states + eval
+        #                 mixer -> (no grad) the target mixer's hyper-networks (they read only the state)
+        #   ONE join, then on this stream the two Double-DQN Q-head launches, the target mixer tail and the loss.
+        # Autograd only ever sees this stream.  Forks taken from a forked stream crash hipStreamEndCapture (ROCm 7.2):
+        # every fork hangs off the capture's origin stream.  MACJD_UPDATE_STREAMS=1 runs everything on one stream.
+        def scan_chain():
+            if shared:
+                gis = [body.gru_input_transform(rows).view(B, T1, J, 3 * H)]                   # networks.py:100
+                h = ops.gru_sequence_multi(gis, [body.rnn.weight_hh], [body.rnn.bias_hh])[0]     # h_0 = 0, qmix.py:241
+                h_alls = [h, h]
+            else:
+                a0, a1 = macs[0].agent, macs[1].agent
+                if rows.is_cuda and a0.fused_gi and a1.fused_gi and not torch.is_grad_enabled():
+                    # fc1 -> ReLU -> W_ih of both controllers: one launch of the dense-chain kernel
+                    gis = [g.view(B, T1, J, 3 * H) for g in ops.mlp_forward_pair(rows, a0.gi_layers(), rows, a1.gi_layers())]
+                else:
+                    gis = [m.agent.gru_input_transform(rows).view(B, T1, J, 3 * H) for m in macs]
+                h_alls = ops.gru_sequence_multi(gis, [m.agent.rnn.weight_hh for m in macs],
+                                                [m.agent.rnn.bias_hh for m in macs])
             return [F.linear(h.reshape(n, H), hd[0][:, :H], m.agent.fc2_q_head[0].bias)
                     for m, h, hd in zip(macs, h_alls, heads)]
-
-        def scan_chain():
-            return bases_of(scan_only())
-
-        def actor_chains():                                                                     # networks.py:127
-            a0, a1 = macs[0].agent, macs[1].agent
-            if rows.is_cuda and a0.fused_actor and a1.fused_actor:   # both controllers' actor chains: one launch
-                return list(ops.mlp_forward_pair(rows, a0.actor_layers(), rows, a1.actor_layers()))
-            return [m.agent.actor_forward(rows) for m in macs]
 
         def double_q(bases, params):
             # a* = argmax_a Q_eval (no mask, qmix.py:138-143), Q_target(a*) (qmix.py:147): two launches, [B,T+1,J]
             return ops.qhead_double_q(bases[1], params[1], heads[1], bases[0], params[0], heads[0], H, A).view(B, T1, J)
-
-        def target_q_tot_of(bases, params, hyper, tq=None):
-            tq = double_q(bases, params) if tq is None else tq
-            return self.target_qmix_net(tq, st["state"], hyper=hyper)                          # [B,T+1,1], qmix.py:151
 
         def eval_forward():
             q_taken = self.mac.agent.get_q_value_for_action(
@@ -313,63 +319,33 @@ class QMixLearner:
                 validate=False).view(B, T1, J)                                                  # qmix.py:161-184
             return self.eval_qmix_net(q_taken, st["state"])                                    # [B,T+1,1], qmix.py:187
 
-        if dev.type == "cuda":
+        two_streams = dev.type == "cuda" and os.environ.get("MACJD_UPDATE_STREAMS", "2") != "1"
+        if two_streams:
             origin = torch.cuda.current_stream(dev)
             if getattr(self, "_target_stream", None) is None:
                 self._target_stream = torch.cuda.Stream(device=dev)
             ts = self._target_stream
-            layout = int(os.environ.get("MACJD_UPDATE_LAYOUT", "6"))   # A/B switch, see the table above
             ts.wait_stream(origin)                                                              # fork
-            params = hyper = tq = None
-            if layout == 3:
-                # as 2, but the origin stream's many short launches are ISSUED between the scan and the rest of the
-                # side stream: a replayed graph feeds its nodes to the GPU in capture order at a few us per node, so
-                # the long scan kernel should go out early and cover the time it takes to issue the origin branch
-                with torch.cuda.stream(ts), torch.no_grad():
-                    h_alls = scan_only()
-                eval_q_tot = eval_forward()
-                with torch.no_grad():
-                    hyper = self.target_qmix_net.hyper_outputs(st["state"])
-                with torch.cuda.stream(ts), torch.no_grad():
-                    bases = bases_of(h_alls)
-                    params = actor_chains()
-            else:
-                with torch.cuda.stream(ts), torch.no_grad():
-                    bases = scan_chain()
-                    if layout == 1:
-                        hyper = self.target_qmix_net.hyper_outputs(st["state"])
-                    if layout in (2, 4, 5):
-                        params = actor_chains()
-                    if layout in (6, 7, 8):   # the two actor chains split between the streams (two single launches)
-                        p_side = macs[0].agent.actor_forward(rows)
-                    if layout == 5:   # the Double-DQN launches read only this stream's results
-                        tq = double_q(bases, params)
-                    if layout == 4:
-                        hyper = self.target_qmix_net.hyper_outputs(st["state"])
-                if layout in (6, 8):
-                    with torch.no_grad():
-                        params = [p_side, macs[1].agent.actor_forward(rows)]
-                        p_side.record_stream(origin)
-                        if layout == 8:   # as 6, the target mixer's hyper-networks issued before the eval forward
-                            hyper = self.target_qmix_net.hyper_outputs(st["state"])
-                if params is None and layout != 7:
-                    with torch.no_grad():
-                        params = actor_chains()
-                eval_q_tot = eval_forward()
+            with torch.cuda.stream(ts), torch.no_grad():
+                bases = scan_chain()
+                p_target = None if shared else macs[0].agent.actor_forward(rows)               # networks.py:127
             with torch.no_grad():
-                if hyper is None:
-                    hyper = self.target_qmix_net.hyper_outputs(st["state"])
-                if layout == 7:   # as 6, the origin stream's actor chain issued last
-                    params = [p_side, macs[1].agent.actor_forward(rows)]
-                    p_side.record_stream(origin)
+                p_eval = body.actor_forward(rows)
+            eval_q_tot = eval_forward()
+            with torch.no_grad():
+                hyper = self.target_qmix_net.hyper_outputs(st["state"])
                 origin.wait_stream(ts)                                                          # join
-                for t_ in list(bases) + ([*hyper] if layout in (1, 4) else []) + ([*params] if layout >= 2 else []) + ([tq] if tq is not None else []):
-                    if torch.is_tensor(t_):
-                        t_.record_stream(origin)
-                target_q_tot = target_q_tot_of(bases, params, hyper, tq)
+                for t_ in list(bases) + ([p_target] if p_target is not None else []):
+                    t_.record_stream(origin)
+                params = [p_eval if shared else p_target, p_eval]
+                target_q_tot = self.target_qmix_net(double_q(bases, params), st["state"], hyper=hyper)   # qmix.py:151
         else:
             with torch.no_grad():
-                target_q_tot = target_q_tot_of(scan_chain(), actor_chains(), self.target_qmix_net.hyper_outputs(st["state"]))
+                bases = scan_chain()
+                p_eval = body.actor_forward(rows)
+                params = [p_eval if shared else macs[0].agent.actor_forward(rows), p_eval]
+                hyper = self.target_qmix_net.hyper_outputs(st["state"])
+                target_q_tot = self.target_qmix_net(double_q(bases, params), st["state"], hyper=hyper)
             eval_q_tot = eval_forward()
         return self._finish_update(st, T, eval_q_tot, target_q_tot)
 
@@ -426,7 +402,7 @@ class QMixLearner:
         return self._pack_stats(loss, grad_norm, ev, tg, sync_stats)
 
     # ------------------------------------------------------------------ HIP-graph path
-    def enable_graphs(self, buffer, batch_size, warmup_iters=3):
+    def enable_graphs(self, buffer, batch_size, warmup_iters=3, force_two_graphs=False):
         """Capture the update as two HIP graphs around the (eager) gradient all-reduce (ONE graph holding both halves
         when there is a single process, i.e. nothing to all-reduce):
           graph A  gather the sampled episodes from the device replay (static index tensor) + both
@@ -487,7 +463,8 @@ class QMixLearner:
                         v.copy_(old) if old is not None else v.zero_()
         self._graph_a, self._graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # a single process has no all-reduce between the two halves: one graph, one launch per update
-        self._g_single = self._world_size() <= 1 and os.environ.get("MACJD_SINGLE_UPDATE_GRAPH", "1") != "0"
+        # (force_two_graphs: the layout every rank of a multi-GPU job runs, for single-process tests)
+        self._g_single = self._world_size() <= 1 and not force_two_graphs
         # thread_local: other threads (RCCL's watchdog polls events) may touch the runtime during capture
         with torch.cuda.graph(self._graph_a, capture_error_mode="thread_local"):
             self._g_out_a = body_a()
@@ -496,6 +473,7 @@ class QMixLearner:
         if not self._g_single:
             with torch.cuda.graph(self._graph_b, pool=self._graph_a.pool(), capture_error_mode="thread_local"):
                 self._g_out_b = self._clip_and_step()
+        self._g_shared_body = self._body_is_shared()   # baked into the captured launches
         self._graphs_ready = True
 
     def train_from_buffer(self, indices=None, sync_stats=True):
@@ -512,6 +490,9 @@ class QMixLearner:
         indices = np.asarray(indices, dtype=np.int64)
         if len(indices) != self._g_B or int(buf.episode_lengths[indices].min()) != self._g_T:
             return self.train(buf.sample(len(indices), indices=indices), None, sync_stats=sync_stats)
+        if self._g_shared_body and not self._body_is_shared():
+            raise RuntimeError("the agent body (fc1 / GRU / actor) of one controller changed after enable_graphs() captured "
+                               "the shared-body update: call enable_graphs() again")
         self.train_step += 1
         # index upload from a small ring of pinned buffers: a copy from pageable memory makes the host wait for the
         # stream (it could then never run ahead of the GPU and every node of the next replay would be issued just in
@@ -541,6 +522,9 @@ class QMixLearner:
         ``hidden_states`` at the final h_T like the reference's loop does."""
         B, T, J, S = obs.shape
         rows = obs.reshape(B * T * J, S)
+        # frozen, identical bodies (see _mark_body_shared): evaluate fc1 / GRU / actor once, the Q-heads per controller
+        shared = len(macs) == 2 and self._body_is_shared() and {id(m) for m in macs} == {id(self.mac), id(self.target_mac)}
+        body_macs = [self.mac] if shared else list(macs)
         side = None
         if rows.is_cuda:
             if getattr(self, "_side_stream", None) is None:
@@ -548,12 +532,14 @@ class QMixLearner:
             side, main = self._side_stream, torch.cuda.current_stream(rows.device)
             side.wait_stream(main)                                           # fork
             with torch.cuda.stream(side):
-                params = [m.agent.actor_forward(rows) for m in macs]         # networks.py:127
+                params = [m.agent.actor_forward(rows) for m in body_macs]    # networks.py:127
         else:
-            params = [m.agent.actor_forward(rows) for m in macs]
-        gis = [m.agent.gru_input_transform(rows).view(B, T, J, 3 * m.agent.rnn_hidden_dim) for m in macs]  # networks.py:100
-        h_alls = ops.gru_sequence_multi(gis, [m.agent.rnn.weight_hh for m in macs],
-                                        [m.agent.rnn.bias_hh for m in macs])  # h_0 = 0 (qmix.py:241)
+            params = [m.agent.actor_forward(rows) for m in body_macs]
+        gis = [m.agent.gru_input_transform(rows).view(B, T, J, 3 * m.agent.rnn_hidden_dim) for m in body_macs]  # networks.py:100
+        h_alls = ops.gru_sequence_multi(gis, [m.agent.rnn.weight_hh for m in body_macs],
+                                        [m.agent.rnn.bias_hh for m in body_macs])  # h_0 = 0 (qmix.py:241)
+        if shared:
+            params, h_alls = params * 2, h_alls * 2
         bases = []
         for m, h_all in zip(macs, h_alls):
             a = m.agent
@@ -589,13 +575,17 @@ class QMixLearner:
     def _update_targets(self):
         self.target_mac.load_state(self.mac.state_dict())
         self.target_qmix_net.load_state_dict(self.eval_qmix_net.state_dict())
+        self._mark_body_shared()
 
     def cuda(self):
+        was_shared = getattr(self, "_body_versions", None) is not None and self._body_is_shared()
         self.mac.cuda()
         self.target_mac.cuda()
         self.eval_qmix_net.cuda()
         self.target_qmix_net.cuda()
         self.device = torch.device("cuda", torch.cuda.current_device())
+        if was_shared:
+            self._mark_body_shared()   # .cuda() re-homes the parameters; equal values stay equal
 
     def save_models(self, path):
         os.makedirs(path, exist_ok=True)

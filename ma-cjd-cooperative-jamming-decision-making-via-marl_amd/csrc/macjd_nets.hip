@@ -847,7 +847,8 @@ extern "C" int macjd_gru_gates(const macjd_grugates_io* io, void* hip_stream) {
     using namespace macjd;
     if (!io || io->n_rows < 0 || io->H < 4 || (io->H & 3) || !io->gi || !io->gh || !io->h || !io->h_out)
         return set_nets_err(MACJD_EINVAL, "macjd_gru_gates: bad argument (H must be a positive multiple of 4)");
-    if (io->gi_ld < 3 * io->H || io->gh_ld < 3 * io->H || io->h_ld < io->H || io->ho_ld < io->H ||
+    // gi_ld == 0: one input-transform row broadcast to every row (static observation shared by all envs / agents)
+    if ((io->gi_ld != 0 && io->gi_ld < 3 * io->H) || io->gh_ld < 3 * io->H || io->h_ld < io->H || io->ho_ld < io->H ||
         (io->h_out2 && io->ho2_ld < io->H))
         return set_nets_err(MACJD_EINVAL, "macjd_gru_gates: row stride smaller than the row");
     if (io->n_rows == 0) return MACJD_OK;

@@ -817,9 +817,8 @@ def layer_norm(x, weight, bias, eps: float = 1e-5):
     return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
 
 
-# A/B switch: the one-output Linear layers (Q-head second layer, mixer V head) ride inside the node that produces
-# their input, so their backward outer product is folded into that node's one backward launch
-FOLD_ROWDOT = os.environ.get("MACJD_FOLD_ROWDOT", "1") != "0"
+# The one-output Linear layers (Q-head second layer, mixer V head) ride inside the node that produces their input, so
+# their backward outer product is folded into that node's one backward launch (measured: DESIGN.md 4.7)
 
 
 def _splitrelu_backward_launch(act, widths, Cp, grads, g_pass, outer):
@@ -902,7 +901,7 @@ def split_relu(x, relu_widths, pass_width: int, dot=None):
     widths = [int(w) for w in relu_widths]
     if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and torch.is_grad_enabled() and x.requires_grad \
             and 1 <= len(widths) <= 4 and not torch.is_autocast_enabled():
-        if dot is not None and FOLD_ROWDOT and _rowdot_ok(x[:, :widths[dot[0]]], dot[1]):
+        if dot is not None and _rowdot_ok(x[:, :widths[dot[0]]], dot[1]):
             return _SplitRelu.apply(x, widths, int(pass_width), int(dot[0]), dot[1], dot[2])
         outs = list(_SplitRelu.apply(x, widths, int(pass_width), -1, None, None))
     else:
@@ -1022,7 +1021,7 @@ class _LinearReluRowDot(torch.autograd.Function):
 
 def linear_relu_dot(x, w1, b1, w2, b2):
     """F.linear(relu(F.linear(x, w1, b1)), w2, b2) for a one-output second layer; one autograd node on a HIP device."""
-    if (FOLD_ROWDOT and _fused_relu_ok(x, w1, b1) and torch.is_grad_enabled() and (w1.requires_grad or w2.requires_grad or x.requires_grad)
+    if (_fused_relu_ok(x, w1, b1) and torch.is_grad_enabled() and (w1.requires_grad or w2.requires_grad or x.requires_grad)
             and x.dim() == 2 and x.shape[0] >= 1024 and w1.shape[0] * w1.shape[1] <= 384 * 256 and x.stride(-1) == 1
             and w2.shape[0] == 1 and w1.shape[0] % 4 == 0 and 4 <= w1.shape[0] <= 1024 and not torch.is_autocast_enabled()):
         return _LinearReluRowDot.apply(x, w1, b1, w2, b2)

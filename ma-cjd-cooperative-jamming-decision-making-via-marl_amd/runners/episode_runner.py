@@ -178,6 +178,9 @@ class BatchedEpisodeRunner:
             "reward": z((T, E, 1), torch.float32), "terminated": z((T, E, 1), torch.bool),
         }
         self._static = bool(getattr(env, "observation_is_static", False))
+        # static observations: the agent's observation-only work (actor chain, fc1 -> W_ih) is done once per episode
+        # batch instead of at every step (BasicMAC.prepare_static_obs); hoist_static_obs = False keeps it per step
+        self.hoist_static_obs = self._static and hasattr(mac, "prepare_static_obs")
         self._static_filled = False
         self._rdpj_sum = z((E, 3), torch.float32)
         self._ep = -1
@@ -198,6 +201,8 @@ class BatchedEpisodeRunner:
         if self._static and not self._static_filled:
             self._fill_static()
         self._rdpj_sum.zero_()
+        if hasattr(self.mac, "prepare_static_obs"):
+            self.mac.prepare_static_obs(self.env.get_obs() if self.hoist_static_obs else None)
         if self._static:
             # the filled staging row is a CONTIGUOUS [E, J, S] copy of the (broadcast) observation: the MAC can
             # view it as [E*J, S] without materialising 2 MB per step; the mask stays the env's broadcast view

@@ -42,7 +42,7 @@ import numpy as np
 ta = tb = 0.0
 for _ in range(N):
     a = time.perf_counter(); learner._graph_a.replay(); b = time.perf_counter()
-    if not learner._g_single:   # one process: both halves are in graph A (set MACJD_SINGLE_UPDATE_GRAPH=0 for two)
+    if not learner._g_single:   # one process: both halves are in graph A (enable_graphs(force_two_graphs=True) for two)
         learner._graph_b.replay()
     c = time.perf_counter()
     ta += b - a; tb += c - b

@@ -331,11 +331,13 @@ def test_gru_sequence_kernel(H, B, T, J):
     assert torch.equal(single, got[0])
 
 
-@pytest.mark.parametrize("T,N,B,steps,single", [(12, 40, 8, 7, "1"), (100, 48, 32, 4, "1"), (100, 48, 32, 4, "0")])
-def test_graphed_train_equals_eager_train(T, N, B, steps, single, monkeypatch):
+@pytest.mark.parametrize("T,N,B,steps,single,shared", [(12, 40, 8, 7, True, "1"), (100, 48, 32, 4, True, "1"),
+                                                       (100, 48, 32, 4, False, "1"), (100, 48, 32, 4, True, "0")])
+def test_graphed_train_equals_eager_train(T, N, B, steps, single, shared, monkeypatch):
     """HIP-graph replay (one graph per update for a single process; two graphs around the gradient all-reduce otherwise,
-    forced here with MACJD_SINGLE_UPDATE_GRAPH=0 so that the layout every rank of a multi-GPU job runs is covered too)
-    of the learner step == the eager step.  HIP-graph replay of the learner step == the eager step: same sampled episodes -> same losses and
+    forced here with force_two_graphs so that the layout every rank of a multi-GPU job runs is covered too; with the
+    frozen agent body evaluated once for both controllers, and — MACJD_SHARED_BODY=0 — once per controller)
+    of the learner step == the eager step: same sampled episodes -> same losses and
     the same weights after several updates incl. a target sync.  The second size is the benchmark's (32 episodes x
     101 steps x 3 agents = 9696 rows): only there do the split-K / grouped weight gradients, the row-dot and the
     fused-ReLU paths engage (they need >= 1024 rows), and every step samples different episodes, so a gradient that
@@ -344,7 +346,7 @@ def test_graphed_train_equals_eager_train(T, N, B, steps, single, monkeypatch):
     from macjd_amd.core.qmix import QMixLearner
     from macjd_amd.utils.replay_buffer import EpisodeReplayBuffer
     from tests_golden_helpers import synthetic_batch
-    monkeypatch.setenv("MACJD_SINGLE_UPDATE_GRAPH", single)
+    monkeypatch.setenv("MACJD_SHARED_BODY", shared)
     g, d = load("3j4r_h64")
     def build():
         args = _gpu_args(d, episode_limit=T, buffer_size=N, batch_size=B, target_update_interval=3)
@@ -363,7 +365,8 @@ def test_graphed_train_equals_eager_train(T, N, B, steps, single, monkeypatch):
         return mac, learner, buf
     mac_e, eager, buf_e = build()
     mac_g, graphed, buf_g = build()
-    graphed.enable_graphs(buf_g, B)   # warm-up updates are undone in place: both start from the same state
+    graphed.enable_graphs(buf_g, B, force_two_graphs=not single)   # warm-up updates are undone in place
+    assert graphed._g_shared_body == (shared == "1")
     rng = np.random.default_rng(1)
     for step in range(steps):
         idx = rng.choice(N, B, replace=False)
@@ -381,6 +384,41 @@ def test_graphed_train_equals_eager_train(T, N, B, steps, single, monkeypatch):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-5, rtol=0, err_msg=k)
     for (k, a), b in zip(eager.target_qmix_net.state_dict().items(), graphed.target_qmix_net.state_dict().values()):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-5, rtol=0, err_msg=k)
+
+
+def test_shared_agent_body_equals_two_controller_unroll(monkeypatch):
+    """Reference-faithful training never changes fc1 / GRU / actor (qmix.py:161-184), and the target controller is a
+    copy (qmix.py:53): the learner evaluates that body ONCE for both networks.  Bitwise equal to the two-controller
+    unroll (different Q-heads, as after training); the sharing stops as soon as either body is written to and comes back
+    with the next hard target sync."""
+    from macjd_amd.core.mac import BasicMAC
+    from macjd_amd.core.qmix import QMixLearner
+    g, d = load("3j4r_h64")
+    args = _gpu_args(d, episode_limit=100)
+    with quiet():
+        mac = BasicMAC(d["S"], args)
+        mac.load_state(sd_from(g, "agent."))
+        learner = QMixLearner(mac, args)
+    with torch.no_grad():   # "trained" eval head: the heads differ, the bodies do not
+        for p in mac.agent.fc2_q_head.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    assert learner._body_is_shared()
+    obs = torch.randn(32, 101, d["J"], d["S"], device=DEV)
+    with torch.no_grad():
+        tq, eq = learner._all_action_q_multi([learner.target_mac, mac], obs)
+        monkeypatch.setenv("MACJD_SHARED_BODY", "0")
+        assert not learner._body_is_shared()
+        tq2, eq2 = learner._all_action_q_multi([learner.target_mac, mac], obs)
+        monkeypatch.delenv("MACJD_SHARED_BODY")
+    assert torch.equal(tq, tq2) and torch.equal(eq, eq2) and not torch.equal(tq, eq)
+    with torch.no_grad():
+        mac.agent.fc1.weight.mul_(1.01)          # e.g. another optimiser training the body
+    assert not learner._body_is_shared()
+    with torch.no_grad():
+        tq3, eq3 = learner._all_action_q_multi([learner.target_mac, mac], obs)
+    assert torch.equal(tq3, tq) and not torch.equal(eq3, eq)   # the target body kept its weights, the eval one moved
+    learner._update_targets()
+    assert learner._body_is_shared()
 
 
 def test_graphed_rollout_equals_eager_rollout():
@@ -421,6 +459,53 @@ def test_graphed_rollout_equals_eager_rollout():
             np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-6, rtol=0, err_msg=k)
         else:
             assert torch.equal(a, b), k
+
+
+@pytest.mark.parametrize("per_env", [False, True])
+def test_static_observation_hoist_gives_identical_buffers(per_env):
+    """The observation never changes within an episode (env.observation_is_static), so the batched runner has the MAC
+    evaluate the actor chain and the fc1 -> W_ih transform once per episode batch (one row when the observation is a
+    broadcast, E rows with per-env scenarios) instead of at each of the 100 steps.  Same kernels on the same row values:
+    every replay key is bit-identical to the per-step evaluation (hoist_static_obs = False), also from a HIP graph."""
+    from macjd_amd.core.mac import BasicMAC
+    from macjd_amd.runners.episode_runner import BatchedEpisodeRunner
+    from macjd_amd.scenario import ScenarioBatch, ring_scenario_dict
+    from macjd_amd.simulation.environment import BatchedElectromagneticEnvironment
+    from macjd_amd.utils.replay_buffer import EpisodeReplayBuffer
+    sc, _ = load_scenario("3j4r")
+    E = 320
+    def build(hoist, graph):
+        if per_env:
+            batch = ScenarioBatch.randomized(ring_scenario_dict(3, 4), E, seed=8)
+            env = BatchedElectromagneticEnvironment(scenario_batch=batch, device=DEV, seed=5)
+        else:
+            env = BatchedElectromagneticEnvironment(scenario=sc, batch_envs=E, device=DEV, seed=5)
+        info = env.get_env_info()
+        d = dict(J=info["n_agents"], A=info["n_actions"], S=info["state_shape"], H=64)
+        args = _gpu_args(d, episode_limit=info["episode_limit"], buffer_size=2 * E, epsilon_start=0.5, epsilon_anneal_time=300)
+        args.env_info = info
+        torch.manual_seed(3)
+        with quiet():
+            mac = BasicMAC(info["obs_shape"], args)
+            mac.cuda()
+            buf = EpisodeReplayBuffer(args)
+        r = BatchedEpisodeRunner(env, mac, buf, args)
+        assert r.hoist_static_obs
+        r.hoist_static_obs = hoist
+        if graph:
+            r.enable_graph()
+        return r, buf, mac
+    runs = [build(True, False), build(False, False), build(True, True)]
+    for ep in range(2):
+        for r, _, _ in runs:
+            r.run(sync_stats=False)
+    assert runs[0][2].static_inputs is not None and runs[1][2].static_inputs is None
+    if not per_env:   # one row, broadcast: nothing of size [E * J, ...] was computed or stored
+        assert runs[0][2].static_inputs[0].stride(0) == 0 and runs[0][2].static_inputs[1].stride(0) == 0
+    for k in runs[0][1].buffers:
+        for other in (1, 2):
+            assert torch.equal(runs[0][1].buffers[k], runs[other][1].buffers[k]), (k, other)
+    assert float(runs[0][1].buffers["hidden_state"].abs().sum()) > 0
 
 
 @pytest.mark.parametrize("N,H", [(1, 64), (63, 64), (12288, 64), (100, 128)])
