@@ -68,31 +68,25 @@ def dist_setup(n_gpus):
 
 
 def cpu_baseline(sc, E, seed, budget_s=12.0):
-    """Times the CPU oracle (oracle/libmacjd_oracle.so, a C port of the reference's env.step; kind="port")
-    on a bounded sample of the same workload.  Single thread: E envs per call (the reference itself is
-    single-threaded Python).  All cores: E envs PER THREAD per call (OpenMP over envs), so every thread
-    steps a full 4096-env batch.  Each leg runs ~budget_s/2 seconds."""
-    import numpy as np
+    """Times the CPU oracle (oracle/libmacjd_oracle.so, a C port of the reference's env.step; kind="port") on a bounded
+    sample of the same workload, INSIDE C on pre-allocated buffers (oracle/macjd_oracle_mt.c, macjd_oracle_bench: one
+    OpenMP region for the whole run, no per-step Python).  Single thread: E envs (the reference itself is
+    single-threaded Python).  All cores: E envs PER THREAD, so every thread steps a full 4096-env batch.  Each leg is
+    sized from a short calibration run to take ~budget_s / 2 seconds."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
-    from _harness import OracleEnv, oracle_lib
-    rng = np.random.default_rng(seed)
-    J, R = sc.num_jammers, sc.num_radars
+    from _harness import oracle_bench, oracle_lib
     out = {}
     cores_all = max(1, min(oracle_lib().macjd_oracle_max_threads(), os.cpu_count() or 1))
+    try:   # threads the cgroup / affinity mask actually gives this process
+        cores_all = max(1, min(cores_all, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        pass
     for label, nt in (("1", 1), ("all", cores_all)):
         n_env = E * nt
-        T = rng.integers(0, 2 * R + 1, size=(n_env, J)).astype(np.int32)
-        P = rng.random((n_env, J)).astype(np.float32)
-        env = OracleEnv(sc, n_env, n_threads=nt)
-        env.step(T, P, seed=seed)  # warm
-        n, t0 = 0, time.perf_counter()
-        while True:
-            env.step(T, P, seed=seed)
-            n += 1
-            dt = time.perf_counter() - t0
-            if dt > budget_s / 2 or n >= 5000:
-                break
-        out[label] = (n_env * n / dt, nt, n, n_env)
+        rate, _ = oracle_bench(sc, n_env, nt, 20, seed=seed)                 # calibration (also warms the threads)
+        n_steps = int(min(20000, max(50, rate * (budget_s / 2) / n_env)))
+        rate, sec = oracle_bench(sc, n_env, nt, n_steps, seed=seed)
+        out[label] = (rate, nt, n_steps, n_env, sec)
     return out
 
 
@@ -110,6 +104,32 @@ def pmc_traffic(J, R, E, per_env=False):
     return None, None
 
 
+def time_graph_replay(fn, dev, calls=20, replays=10):
+    """Average microseconds per call of ``fn`` (a launch sequence on the current stream), replayed from a HIP graph and
+    bracketed by events on the replay stream."""
+    import torch
+    with torch.no_grad():
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fn()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for _ in range(calls):
+                fn()
+        gr.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(replays):
+            gr.replay()
+        e1.record()
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (calls * replays) * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +142,8 @@ def main():
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--sweep", action="store_true", help="also print an E-sweep of the env kernel (stderr)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-modes", dest="no_other_modes", action="store_true",
+                    help="measure only --mode (default: the other two modes of SURVEY.md 8(d) are timed briefly as well)")
     ap.add_argument("--per-env-scenarios", dest="per_env", action="store_true",
                     help="every env gets its own randomised scenario (positions / threat / powers): tables streamed from HBM")
     ap.add_argument("--no-graphs", dest="no_graphs", action="store_true", help="eager launches (A/B against HIP graphs)")
@@ -136,6 +158,14 @@ def main():
         entry.build()
     if world > 1:
         torch.distributed.barrier()
+    # what ran where (the driver reads this to see that RCCL really had N ranks on N devices)
+    dist_info = {"world_size": world, "backend": torch.distributed.get_backend() if world > 1 else None,
+                 "devices": [torch.cuda.current_device()]}
+    if world > 1:
+        devs = [None] * world
+        torch.distributed.all_gather_object(devs, {"rank": rank, "local_rank": local, "device": torch.cuda.current_device(),
+                                                   "name": torch.cuda.get_device_name(torch.cuda.current_device())})
+        dist_info["devices"] = devs
     from macjd_amd.scenario import Scenario, ring_scenario_dict
     from macjd_amd.simulation.environment import BatchedElectromagneticEnvironment
 
@@ -154,12 +184,17 @@ def main():
                 raise
         mode = ("train" if bench_mod is not None else "env") if mode == "auto" else mode
 
+    batch = None
     if args.per_env:
         from macjd_amd.scenario import ScenarioBatch
         batch = ScenarioBatch.randomized(ring_scenario_dict(J, R), E, seed=42, env_offset=rank * E)
-        env = BatchedElectromagneticEnvironment(scenario_batch=batch, device=dev, seed=42, env_offset=rank * E)
-    else:
-        env = BatchedElectromagneticEnvironment(scenario=sc, batch_envs=E, device=dev, seed=42, env_offset=rank * E)
+
+    def make_env():
+        if args.per_env:
+            return BatchedElectromagneticEnvironment(scenario_batch=batch, device=dev, seed=42, env_offset=rank * E)
+        return BatchedElectromagneticEnvironment(scenario=sc, batch_envs=E, device=dev, seed=42, env_offset=rank * E)
+
+    env = make_env()
     env.reset()
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     # synthetic actions, agent-major storage [J, E] (T ~ U{0..2R}, P ~ U[0,1))
@@ -172,27 +207,47 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    if mode == "env":
-        def step_fn(i):
-            if i % sc.episode_limit == 0:
-                env.reset()
-            env.step(T, P)
-        extra = {}
-    else:
-        step_fn, extra = bench_mod.make_step(args, sc, env, dev, rank, world, mode)
+    def build_step(which, env_, cli):
+        if which == "env":
+            def fn(i):
+                if i % sc.episode_limit == 0:
+                    env_.reset()
+                env_.step(T, P)
+            return fn, {}
+        return bench_mod.make_step(cli, sc, env_, dev, rank, world, which)   # aligns its episodes to cli.warmup / cli.steps
 
-    for i in range(args.warmup):
-        step_fn(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step_fn(args.warmup + i)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+    def timed(fn, warmup, steps):
+        for i in range(warmup):
+            fn(i)
+        barrier()
+        t0_ = time.perf_counter()
+        for i in range(steps):
+            fn(warmup + i)
+        barrier()
+        d = time.perf_counter() - t0_
+        if world > 1:
+            tt = torch.tensor([d], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            d = float(tt.item())
+        return d
+
+    step_fn, extra = build_step(mode, env, args)
+    dt = timed(step_fn, args.warmup, args.steps)
+
+    # ---- the other two modes of SURVEY.md 8(d) in the same run (single process; shorter regions) ----
+    modes = {mode: round(dt / args.steps * 1e3, 4)}
+    if world == 1 and bench_mod is not None and not args.no_other_modes:
+        for which in ("env", "rollout", "train"):
+            if which in modes:
+                continue
+            e2 = make_env()
+            e2.reset()
+            cli2 = argparse.Namespace(**vars(args))
+            cli2.steps, cli2.warmup = (300, 100) if which != "env" else (1000, 100)
+            fn2, _ = build_step(which, e2, cli2)
+            modes[which] = round(timed(fn2, cli2.warmup, cli2.steps) / cli2.steps * 1e3, 4)
+            del fn2
+            torch.cuda.synchronize()
 
     # ---- roofline of the env-step kernel: HIP events on the launch stream ----
     ms = env.time_step_kernel(T, P, iters=200)
@@ -204,6 +259,9 @@ def main():
                 "kernel": (f"env_step_kernel<{J},{R},per-env tables>" if args.per_env else
                            f"env_step_slots_kernel<{J},{R}>" if E < (1 << 17) else f"env_step_kernel<{J},{R}>"),
                 "us_per_launch": round(ms * 1e3, 3),
+                "timing": "HIP events around 200 launches replayed from one HIP graph on their own stream (macjd_env_step_timed); "
+                          "the rocprofv3 kernel-trace average of the same replay is committed under profiles/ (r02_bench_env_roofline_*)",
+                "traffic_measured_in_run": False,
                 "bytes_per_env_step": B_step, "envs_per_launch": E}
     # large-batch point of the same kernel family (2^22 envs): the HBM-bound asymptote, measured every run so the
     # launch-bound fraction at the benchmark's E is not mistaken for the kernel's streaming rate
@@ -274,6 +332,14 @@ def main():
                                                 "frac": round(tfb / 157.3, 4)}
         except Exception as ex:  # the HBM roofline above is the contract item; this one is additional
             roofline_mfma = {"error": str(ex)[:200]}
+    # ---- MFMA fraction of the mixer's hyper_w_1 network (2 M (S 128 + 128 J 64) flop over the learner's
+    # M = batch x (T + 1) rows) as the learner evaluates it ----
+    roofline_mixer = None
+    if rank == 0 and bench_mod is not None:
+        try:
+            roofline_mixer = bench_mod.mixer_hyper_w1_roofline(sc, args.hidden, dev, 32 * (sc.episode_limit + 1), time_graph_replay)
+        except Exception as ex:
+            roofline_mixer = {"error": str(ex)[:200]}
     sweep = None
     if args.sweep and rank == 0:
         sweep = []
@@ -307,21 +373,33 @@ def main():
                                    + (", per-env randomised scenarios" if args.per_env else ""),
                        "mode": mode, "per_gpu_env_steps_per_s": round(E * args.steps / dt, 1), **extra},
             "roofline": roofline,
+            # ms per batched step of each mode of SURVEY.md 8(d): (i) env kernel only, (ii) rollout, (iii) rollout + training
+            "modes_ms_per_step": modes,
         }
+        if "train" in modes:
+            upd = extra.get("train_calls_per_step", 1) if mode == "train" else 1
+            res["updates_per_s"] = round(world * upd / (modes["train"] * 1e-3), 1)
+            res["train_env_ratio"] = ("1 learner update (32 whole episodes) per BATCHED env step = 1 update / %d env-steps per GPU; "
+                                      "the reference does 1 update / 1 env-step of its single env (main.py:212-216) — at that ratio "
+                                      "the rate is bounded by 1 / update time = updates_per_s env-steps/s per GPU" % E)
+        res["distributed"] = dist_info
         if world > 1 and os.environ.get("MACJD_BENCH_ONE_GPU_REHEARSAL") == "1":
             res["config"]["rehearsal"] = "all ranks on ONE GPU over gloo: code-path check only, not a measurement"
         if roofline_mfma is not None:
             res["roofline_mfma"] = roofline_mfma
+        if roofline_mixer is not None:
+            res["roofline_mfma_mixer"] = roofline_mixer
         if sweep:
             res["env_kernel_sweep"] = sweep
         if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N=1 only
             cb = cpu_baseline(sc, E, seed=42)
             res["cpu_baseline"] = {
                 "value": round(cb["all"][0], 1), "unit": "env-steps/s", "cores": cb["all"][1], "kind": "port",
-                "sample": (f"C port (oracle) of reference env.step only, Philox uniforms: {cb['all'][3]} envs x "
-                           f"{cb['all'][2]} steps on {cb['all'][1]} OpenMP threads; single thread: {cb['1'][3]} envs x "
-                           f"{cb['1'][2]} steps"),
+                "sample": (f"C port (oracle) of reference env.step only, Philox uniforms, timed inside C on pre-allocated "
+                           f"buffers: {cb['all'][3]} envs x {cb['all'][2]} steps on {cb['all'][1]} OpenMP threads "
+                           f"({cb['all'][4]:.1f} s); single thread: {cb['1'][3]} envs x {cb['1'][2]} steps ({cb['1'][4]:.1f} s)"),
                 "single_core_value": round(cb["1"][0], 1),
+                "thread_scaling": round(cb["all"][0] / cb["1"][0], 2),
                 "note": "covers env.step only; the Python reference measured in the build container (BASELINE.md): "
                         "8725 env.step/s, 626 env-steps/s full rollout, ~1 env-step/s at its 1-train-per-step cadence"}
         print(json.dumps(res), flush=True)

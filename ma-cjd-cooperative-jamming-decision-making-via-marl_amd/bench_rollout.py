@@ -112,3 +112,29 @@ def make_step(cli, sc, env, dev, rank, world, mode):
              "train_calls_per_step": 1 if mode == "train" else 0, "hip_graphs": bool(use_graphs), "gemm_tuning": bool(gemm_tuning),
              "replay_capacity_episodes": args.buffer_size}
     return step_fn, extra
+
+
+def mixer_hyper_w1_roofline(sc, hidden, dev, M, timer, peak_tflops=157.3):
+    """MFMA fraction of the mixer's ``hyper_w_1`` network (reference core/networks.py:223-248), the figure SURVEY.md 8(d)
+    asks for: 2 M (S Hh + Hh J Em) flop over the learner's M = batch x (T + 1) rows, timed as the learner evaluates the
+    state-only half of the mixer (``QMixer.hyper_outputs``: LayerNorm + all four hyper-networks, of which hyper_w_1 is
+    ~85 % of the flops) and, separately, hyper_w_1 alone.  ``timer(fn, dev)`` -> microseconds per call."""
+    from .core.networks import QMixer
+    args = make_args(sc, hidden, dev)
+    torch.manual_seed(0)
+    mixer = QMixer(args).to(dev)
+    S, J, Hh, Em = mixer.state_dim, mixer.n_agents, mixer.hyper_hidden_dim, mixer.embed_dim
+    s = torch.randn(M, S, device=dev)
+    flops_w1 = 2.0 * M * (S * Hh + Hh * J * Em)
+    flops_all = flops_w1 + 2.0 * M * (S * Hh + Hh * Em) + 2.0 * M * S * Em + 2.0 * M * (S * Em + Em)
+    with torch.no_grad():
+        us_w1 = timer(lambda: mixer.hyper_w_1(s), dev)
+        us_all = timer(lambda: mixer.hyper_outputs(s), dev)
+    tf = flops_w1 / (us_w1 * 1e-6) / 1e12
+    return {"bound": "mfma", "achieved": round(tf, 2), "peak": peak_tflops, "unit": "TFLOP/s", "frac": round(tf / peak_tflops, 4),
+            "traffic": None, "kernel": "QMixer.hyper_w_1 (%d-%d-%d, %d rows)" % (S, Hh, J * Em, M),
+            "us_per_call": round(us_w1, 2), "flops_per_call": int(flops_w1), "dtype": "f32",
+            "hyper_outputs": {"us_per_call": round(us_all, 2), "flops_per_call": int(flops_all),
+                              "achieved": round(flops_all / (us_all * 1e-6) / 1e12, 2),
+                              "frac": round(flops_all / (us_all * 1e-6) / 1e12 / peak_tflops, 4),
+                              "what": "LayerNorm + the four hyper-networks (everything of the mixer that reads only the state)"}}

@@ -187,6 +187,9 @@ class QMixLearner:
         tr = self._trainable()
         if self._flat_grad is None:
             self._flat_grad = torch.empty(sum(p.numel() for p in tr), dtype=tr[0].dtype, device=tr[0].device)
+        for p in tr:   # an empty loss (max_seq_len <= 1) reaches nothing: the reference then steps on NaN / None
+            if p.grad is None:   # gradients (qmix.py:190-200); here the missing ones count as zero
+                p.grad = torch.zeros_like(p)
         base, esz, off, in_place = self._flat_grad.data_ptr(), self._flat_grad.element_size(), 0, 0
         for p in tr:
             in_place += int(p.grad is not None and p.grad.data_ptr() == base + off * esz and p.grad.is_contiguous())
@@ -355,7 +358,7 @@ class QMixLearner:
             p.grad = None
         if eval_q_tot.is_cuda:
             # the loss kernel also produces dL/dQ_tot: it seeds the backward pass directly (no ones-fill / multiply)
-            loss, eval_mean, target_mean, gy = ops.td_loss_and_grad(
+            loss, eval_mean, target_mean, gy, self._last_stats4 = ops.td_loss_and_grad(
                 eval_q_tot, target_q_tot, st["reward"], st["terminated"], st["filled"], self.args.gamma, T - 1, 1)
             # the weight gradients: one grouped launch pair after the chain, written into the flat gradient vector
             with ops.deferred_wgrad(grad_dst=getattr(self, "_grad_dst", None)):
@@ -399,7 +402,12 @@ class QMixLearner:
         self._allreduce_grads()
         grad_norm = self._clip_and_step()
         self._after_step()
+        if not sync_stats and torch.is_tensor(grad_norm) and grad_norm is self._grad_norm_tensor():
+            grad_norm = grad_norm.clone()   # the fused optimiser step reuses ONE output tensor: hand out a snapshot
         return self._pack_stats(loss, grad_norm, ev, tg, sync_stats)
+
+    def _grad_norm_tensor(self):
+        return getattr(self, "_grad_norm", None)
 
     # ------------------------------------------------------------------ HIP-graph path
     def enable_graphs(self, buffer, batch_size, warmup_iters=3, force_two_graphs=False):
@@ -443,6 +451,7 @@ class QMixLearner:
         # Eager warm-up on a side stream: allocates the optimiser state BEFORE capture (state created during
         # capture would be re-initialised by every replay) and lets the libraries pick their kernels.  The
         # warm-up updates are then undone in place, so enabling graphs does not change the training state.
+        was_shared = self._body_is_shared()
         snap_p = [p.detach().clone() for p in self.params]
         snap_o = {id(p): {k: v.clone() for k, v in st.items() if torch.is_tensor(v)}
                   for p, st in self.optimizer.state.items()}
@@ -461,6 +470,8 @@ class QMixLearner:
                     if torch.is_tensor(v):
                         old = snap_o.get(id(p), {}).get(k)
                         v.copy_(old) if old is not None else v.zero_()
+        if was_shared:
+            self._mark_body_shared()   # the restore wrote the (unchanged) body values back: still identical
         self._graph_a, self._graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # a single process has no all-reduce between the two halves: one graph, one launch per update
         # (force_two_graphs: the layout every rank of a multi-GPU job runs, for single-process tests)
@@ -468,6 +479,13 @@ class QMixLearner:
         # thread_local: other threads (RCCL's watchdog polls events) may touch the runtime during capture
         with torch.cuda.graph(self._graph_a, capture_error_mode="thread_local"):
             self._g_out_a = body_a()
+            # the four logged scalars of an update end up in ONE static [4] tensor: the loss kernel writes (loss,
+            # mean Q_tot, mean target, mask sum) and the optimiser step then overwrites the unused mask sum with the
+            # gradient norm — train_from_buffer(stats_row=...) snapshots it with a single 16-byte copy
+            st4 = getattr(self, "_last_stats4", None) if fused else None
+            if st4 is not None and st4.numel() == 4:
+                self._grad_norm = st4[3]
+            self._g_stats4 = st4 if (st4 is not None and st4.numel() == 4) else None
             if self._g_single:
                 self._g_out_b = self._clip_and_step()
         if not self._g_single:
@@ -476,8 +494,11 @@ class QMixLearner:
         self._g_shared_body = self._body_is_shared()   # baked into the captured launches
         self._graphs_ready = True
 
-    def train_from_buffer(self, indices=None, sync_stats=True):
-        """Sample ``batch_size`` whole episodes (np.random.choice like the reference's buffer) and update."""
+    def train_from_buffer(self, indices=None, sync_stats=True, stats_row=None):
+        """Sample ``batch_size`` whole episodes (np.random.choice like the reference's buffer) and update.
+        With ``sync_stats=False`` the returned scalars are views of the captured graph's static output tensors, which
+        the NEXT update overwrites; pass ``stats_row`` (float32 [4] on the device) to receive this update's
+        (loss, eval_qtot_avg, target_qtot_avg, grad_norm) as a snapshot instead (one 16-byte device copy, no sync)."""
         buf = self._g_buffer if getattr(self, "_graphs_ready", False) else None
         if buf is None:
             raise RuntimeError("call enable_graphs(buffer, batch_size) first")
@@ -486,10 +507,12 @@ class QMixLearner:
             # learner's own numpy Generator: the legacy np.random.choice shuffles the whole population per call
             # (~90 us for 8192 stored episodes — more host time than the rest of the update's launch), Generator.choice
             # takes ~4 us.  EpisodeReplayBuffer.sample() keeps the reference's call.
+            if buf.current_size < self._g_B:   # fewer stored episodes than a batch: sample what is there, like
+                return self._snap(self.train(buf.sample(self._g_B), None, sync_stats=sync_stats), stats_row)   # buffer.sample does
             indices = self._sample_rng.choice(buf.current_size, self._g_B, replace=False)
         indices = np.asarray(indices, dtype=np.int64)
         if len(indices) != self._g_B or int(buf.episode_lengths[indices].min()) != self._g_T:
-            return self.train(buf.sample(len(indices), indices=indices), None, sync_stats=sync_stats)
+            return self._snap(self.train(buf.sample(len(indices), indices=indices), None, sync_stats=sync_stats), stats_row)
         if self._g_shared_body and not self._body_is_shared():
             raise RuntimeError("the agent body (fc1 / GRU / actor) of one controller changed after enable_graphs() captured "
                                "the shared-body update: call enable_graphs() again")
@@ -509,7 +532,20 @@ class QMixLearner:
             self._graph_b.replay()
         self._after_step()
         loss, ev, tg = self._g_out_a
-        return self._pack_stats(loss, self._g_out_b, ev, tg, sync_stats)
+        if stats_row is not None and not sync_stats and self._g_stats4 is not None:
+            stats_row.copy_(self._g_stats4, non_blocking=True)
+            return {"loss": stats_row[0], "grad_norm": stats_row[3], "eval_qtot_avg": stats_row[1], "target_qtot_avg": stats_row[2]}
+        return self._snap(self._pack_stats(loss, self._g_out_b, ev, tg, sync_stats), stats_row)
+
+    @staticmethod
+    def _snap(stats, stats_row):
+        """Copy device-resident scalars of ``stats`` into ``stats_row`` (see train_from_buffer) and return views of it."""
+        if stats_row is None or not torch.is_tensor(stats["loss"]):
+            return stats
+        order = ("loss", "eval_qtot_avg", "target_qtot_avg", "grad_norm")
+        torch.stack([torch.as_tensor(stats[k], device=stats_row.device, dtype=torch.float32).reshape(()) for k in order],
+                    out=stats_row)
+        return {k: stats_row[i] for i, k in enumerate(order)}
 
     def _all_action_q_multi(self, macs, obs, keep_final_hidden=True):
         """Q(s_t, a, P_a(s_t)) for every discrete action, [B, T, J, A] per controller; replaces the

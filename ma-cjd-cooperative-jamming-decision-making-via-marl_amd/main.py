@@ -9,14 +9,22 @@ Same entry points and behaviour as reference ``main.py:50-328``:
 
 What is added (build flags, all optional):
   ``batch_envs``  (default 1)  E > 1 switches to the batched device-resident runner: one ``runner.run()`` is E
-                  episodes.  The learner then does ``episode_len // train_interval`` updates per ROLLOUT (the
-                  reference does that many per episode; with ``batch_envs = 1`` the two coincide exactly).
+                  episodes.  The learner then does ``updates_per_rollout`` updates per ROLLOUT (default
+                  ``episode_len // train_interval``: what the reference does per EPISODE, main.py:212-216; with
+                  ``batch_envs = 1`` the two coincide exactly).  Update-to-data ratio: the reference samples
+                  32 x 100 transitions per env step it collects; at E = 4096 and 100 updates per rollout this driver
+                  samples 0.78 transitions per collected transition — config/default.yaml scales ``total_env_steps``
+                  and ``epsilon_anneal_time`` so that a default run still makes ~49 k updates (reference: ~19 k) and
+                  anneals epsilon over the first 5 % of the run like the reference.
+  ``torchrun``    one process per GPU: envs shard over ranks (``env_offset = rank * batch_envs``), weights are
+                  broadcast from rank 0, every update all-reduces the flat gradient (RCCL); rank 0 logs and saves.
   ``hip_graphs``  (default True on a HIP device with batch_envs > 1) replay rollouts / updates from HIP graphs.
   ``randomize_scenarios`` / ``--randomize-scenarios`` (batched runs): every env trains on its own random variation
                   of the scenario file (positions, threat levels, powers; ``scenario.ScenarioBatch``).
   ``--resume DIR`` restores agent, mixer, optimiser and ``trainer_state.json`` (env steps, episodes, epsilon
-                  clock, learner step counters) — the reference saves the optimiser but never loads it and has
-                  no resume path (``core/qmix.py:317-333``).
+                  clock, learner step counters, and the positions of the three random streams: exploration counter,
+                  replay sampler, per-env Monte-Carlo episode index) — the reference saves the optimiser but never
+                  loads it and has no resume path (``core/qmix.py:317-333``).
   ``test_interval`` / ``test_nepisodes`` (present but unread in the reference's ``default.yaml:81-83``): greedy
                   evaluation episodes reporting return, radar lock fraction and mean power (the paper's
                   metrics, ``docs/impadd.md:60-64``).
@@ -84,9 +92,10 @@ class ScalarLog:
             self._tb.close()
 
 
-def _pick_device(args):
+def _pick_device(args, local_rank=0):
     requested = str(getattr(args, "device_request", getattr(args, "device", "cuda"))).lower()
     if requested.startswith("cuda") and torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
         device = torch.device("cuda")
     else:
         if requested.startswith("cuda"):
@@ -139,7 +148,13 @@ def save_checkpoint(learner, runner, save_dir, episode, total_steps):
     learner.save_models(save_dir)
     state = {"episode": episode, "total_steps": total_steps, "t_env": runner.t_env,
              "train_step": learner.train_step, "last_target_update_step": learner.last_target_update_step,
-             "epsilon": learner.mac.action_selector.epsilon}
+             "epsilon": learner.mac.action_selector.epsilon,
+             # positions of the random streams (plain ints: JSON, nothing pickled)
+             "runner_ep": int(getattr(runner, "_ep", -1)),
+             "sample_rng": learner._sample_rng.bit_generator.state}
+    ep_idx = getattr(runner.env, "episode_index", None)
+    if ep_idx is not None:
+        state["env_episode"] = int(ep_idx.max().item())
     with open(os.path.join(save_dir, "trainer_state.json"), "w") as f:
         json.dump(state, f)
 
@@ -158,6 +173,12 @@ def load_checkpoint(learner, runner, load_dir):
         learner.train_step = int(state.get("train_step", 0))
         learner.last_target_update_step = int(state.get("last_target_update_step", 0))
         learner.mac.action_selector.epsilon = float(state.get("epsilon", learner.mac.action_selector.epsilon))
+        if "runner_ep" in state and hasattr(runner, "_ep"):
+            runner._ep = int(state["runner_ep"])
+        if "sample_rng" in state:
+            learner._sample_rng.bit_generator.state = state["sample_rng"]
+        if "env_episode" in state and getattr(runner.env, "episode_index", None) is not None:
+            runner.env.episode_index.fill_(int(state["env_episode"]))
     return state
 
 
@@ -178,12 +199,16 @@ def evaluate(runner, n_episodes):
 
 
 def run(args):
-    device = _pick_device(args)
-    print(f"Using device: {args.device}")
-    np.random.seed(args.seed)
-    torch.manual_seed(args.seed)
+    from . import parallel
+    rank, world, local_rank = parallel.init_distributed()   # no-op unless launched by torchrun (WORLD_SIZE > 1)
+    device = _pick_device(args, local_rank)
+    print(f"Using device: {args.device}" + (f" (rank {rank} of {world}, local device {local_rank})" if world > 1 else ""))
+    np.random.seed(args.seed + rank)   # replay sampling stream of this rank's shard
+    torch.manual_seed(args.seed)       # identical initial weights on every rank (broadcast below as well)
     if args.use_cuda:
         torch.cuda.manual_seed(args.seed)
+    if world > 1:
+        args.env_offset = rank * int(getattr(args, "batch_envs", 1) or 1)
     test_name = getattr(args, "test_name", "ma_cjd_test")
     run_name = f"run_{datetime.now().strftime('%Y%m%d_%H%M%S')}"
     log_dir = os.path.join(getattr(args, "results_path", "logs") or "logs", test_name, run_name)
@@ -195,6 +220,11 @@ def run(args):
         from . import ops
         ops.enable_gemm_tuning(os.path.join(log_dir, "tunableop_results.csv"))
     env, mac, buffer, learner, runner = build_components(args, sim_config_path)
+    if world > 1:
+        mac.select_seed = int(args.seed) + 1000 * rank          # every rank explores with its own stream
+        learner._sample_rng = np.random.default_rng(int(args.seed) + rank)
+        parallel.broadcast_parameters([mac.agent, learner.eval_qmix_net])
+        learner._update_targets()
     batch_envs = int(getattr(args, "batch_envs", 1) or 1)
     episodes_per_run = batch_envs
     use_graphs = bool(getattr(args, "hip_graphs", True)) and args.use_cuda and batch_envs > 1
@@ -234,11 +264,14 @@ def run(args):
                 learner.enable_graphs(buffer, args.batch_size)
                 runner.enable_graph()
                 graphs_on = True
-            num_train_steps = current_episode_steps // args.train_interval
+            num_train_steps = int(getattr(args, "updates_per_rollout", 0) or current_episode_steps // args.train_interval)
             pending = []
-            for _ in range(num_train_steps):
+            # every update's four scalars are snapshotted into their own row on the device (the graphed update reuses
+            # ONE static output tensor): read back once after the block
+            hist = torch.empty((num_train_steps, 4), dtype=torch.float32, device=device) if graphs_on else None
+            for i_upd in range(num_train_steps):
                 if graphs_on:
-                    pending.append(learner.train_from_buffer(sync_stats=False))
+                    pending.append(learner.train_from_buffer(sync_stats=False, stats_row=hist[i_upd]))
                 else:
                     batch = buffer.sample(args.batch_size)
                     if batch is not None:
@@ -291,7 +324,7 @@ def run(args):
             last_log_time = now
 
         boundary = (episode // args.save_interval) != ((episode - episodes_per_run) // args.save_interval)
-        if args.save_model and (boundary or total_steps >= args.total_env_steps):          # main.py:283-289
+        if args.save_model and rank == 0 and (boundary or total_steps >= args.total_env_steps):          # main.py:283-289
             if total_steps > args.start_training_steps:
                 save_dir = os.path.join(args.save_model_dir, test_name, f"step_{total_steps}")
                 print(f"Saving model to {save_dir}")
@@ -300,6 +333,8 @@ def run(args):
     if hasattr(env, "close") and callable(env.close):
         env.close()
     writer.close()
+    if world > 1:
+        torch.distributed.barrier()
     print("Training finished.")
     return {"episodes": episode, "total_steps": total_steps, "log_dir": log_dir, "train_steps": learner.train_step}
 

@@ -488,12 +488,13 @@ def td_loss_full(y_full, tq_full, reward, terminated, filled, gamma, Tm1, tq_off
 
 
 def td_loss_and_grad(y_full, tq_full, reward, terminated, filled, gamma, Tm1, tq_off):
-    """(loss, mean(y), mean(target), dL/dy [B, Ty, 1]) in one launch, nothing recorded for autograd: the caller seeds
+    """(loss, mean(y), mean(target), dL/dy [B, Ty, 1], the kernel's [4] output tensor (loss, mean y, mean target, mask
+    sum)) in one launch, nothing recorded for autograd: the caller seeds
     the backward pass with the gradient itself (``y_full.backward(gy)``) — ``loss.backward()`` would first fill a
     ones tensor for the scalar and multiply the saved gradient by it (three launch-bound kernels)."""
     with torch.no_grad():
         _, stats = _TdLossHip.apply(y_full, tq_full, reward, terminated, filled, gamma, Tm1, tq_off)
-    return stats[0], stats[1], stats[2], stats.saved_gy
+    return stats[0], stats[1], stats[2], stats.saved_gy, stats
 
 
 def td_loss(y, tq, reward, terminated, filled, gamma):

@@ -267,6 +267,10 @@ class BatchedEpisodeRunner:
             self._eps_sched = torch.zeros(T, dtype=torch.float32, device=dev)
             self._ctr_base = torch.zeros(1, dtype=torch.int64, device=dev)
         t_env0, ep0 = self.t_env, self._ep
+        # the warm-up rollout resets the envs: put their episode indices (Monte-Carlo stream position) back afterwards,
+        # so that enabling a graph does not change which values the following episodes draw
+        env_ep = getattr(self.env, "episode_index", None)
+        env_ep0 = env_ep.clone() if env_ep is not None else None
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):  # warm-up outside capture
@@ -279,6 +283,8 @@ class BatchedEpisodeRunner:
         self._graphs[n] = graph
         if n == T:
             self._graph = graph
+        if env_ep0 is not None:
+            env_ep.copy_(env_ep0)
         self.t_env, self._ep = t_env0, ep0
         self.mac.device_schedule = None
 

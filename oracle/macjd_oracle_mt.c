@@ -6,6 +6,7 @@
  */
 #include <stddef.h>
 #include <stdint.h>
+#include <time.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -63,5 +64,41 @@ int macjd_oracle_env_step_mt(const macjd_scenario_desc* d, const macjd_step_io* 
             }
         }
     }
+    return rc;
+}
+
+/*
+ * CPU baseline timing for bench.py: n_steps consecutive env steps of all io->n_envs environments, timed INSIDE C on
+ * the caller's pre-allocated buffers (no per-step Python, no allocation).  One parallel region for the whole run:
+ * thread t owns a contiguous slice of the envs and steps it n_steps times (envs are independent, so no barrier is
+ * needed between steps); the step counters are rewound every `episode_limit` steps like a reset would.  Returns the
+ * wall time of the region in *seconds (max over threads by construction: the region ends when the last one does).
+ */
+int macjd_oracle_bench(const macjd_scenario_desc* d, const macjd_step_io* io, int n_threads, int n_steps, double* seconds) {
+    if (n_threads < 1) n_threads = 1;
+    if (n_steps < 1 || !seconds) return MACJD_EINVAL;
+    const int64_t E = io->n_envs;
+    int rc = 0;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+    for (int t = 0; t < n_threads; ++t) {
+        int64_t lo = E * t / n_threads, hi = E * (t + 1) / n_threads;
+        if (hi > lo) {
+            macjd_step_io s = slice(d, io, lo, hi - lo);
+            for (int k = 0; k < n_steps; ++k) {
+                if (k % d->episode_limit == 0)
+                    for (int64_t e = 0; e < s.n_envs; ++e) s.step[e] = 0;
+                int r = macjd_oracle_env_step(d, &s, NULL);
+                if (r != 0) {
+#pragma omp critical
+                    rc = r;
+                    break;
+                }
+            }
+        }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
     return rc;
 }

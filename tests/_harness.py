@@ -62,6 +62,9 @@ def oracle_lib():
         lib.macjd_oracle_detection_probability.restype = ctypes.c_double
         lib.macjd_oracle_detection_probability.argtypes = [ctypes.c_void_p, ctypes.c_double]
         lib.macjd_oracle_max_threads.restype = ctypes.c_int
+        lib.macjd_oracle_bench.restype = ctypes.c_int
+        lib.macjd_oracle_bench.argtypes = [ctypes.c_void_p, ctypes.POINTER(StepIO), ctypes.c_int, ctypes.c_int,
+                                           ctypes.POINTER(ctypes.c_double)]
         _oracle = lib
     return _oracle
 
@@ -137,6 +140,36 @@ class OracleEnv:
         out["track"] = self.track.copy()
         out["step"] = self.step_count.copy()
         return out
+
+
+def oracle_bench(scenario, n_envs, n_threads, n_steps, seed=0):
+    """Times ``n_steps`` env steps of ``n_envs`` environments inside C (macjd_oracle_bench): pre-allocated buffers,
+    Philox uniforms, synthetic actions (T ~ U{0..2R}, P ~ U[0,1)), the same outputs the HIP kernel writes.
+    Returns env-steps / second."""
+    E, R, J = int(n_envs), scenario.num_radars, scenario.num_jammers
+    rng = np.random.default_rng(seed)
+    desc, keep = scenario.c_desc()
+    T = rng.integers(0, 2 * R + 1, size=(E, J)).astype(np.int32)
+    P = rng.random((E, J)).astype(np.float32)
+    bufs = {"track": np.zeros((E, R), np.uint8), "step": np.zeros(E, np.int32), "episode": np.zeros(E, np.int32),
+            "reward": np.zeros(E, np.float32), "r_dpj": np.zeros((E, 3), np.float32), "terminated": np.zeros(E, np.uint8),
+            "pd": np.zeros((E, R), np.float32), "snr": np.zeros((E, R), np.float32)}
+    io = StepIO()
+    io.n_envs, io.env_offset, io.seed, io.flags = E, 0, seed, 0
+    io.T, io.T_se, io.T_sx = T.ctypes.data, J, 1
+    io.P32, io.P64, io.P_se, io.P_sx = P.ctypes.data, None, J, 1
+    io.episode = bufs["episode"].ctypes.data
+    io.track, io.k_se, io.k_sx = bufs["track"].ctypes.data, R, 1
+    io.step = bufs["step"].ctypes.data
+    io.reward, io.r_dpj, io.terminated = bufs["reward"].ctypes.data, bufs["r_dpj"].ctypes.data, bufs["terminated"].ctypes.data
+    io.pd, io.pd_se, io.pd_sx = bufs["pd"].ctypes.data, R, 1
+    io.snr_with, io.sw_se, io.sw_sx = bufs["snr"].ctypes.data, R, 1
+    sec = ctypes.c_double(0.0)
+    rc = oracle_lib().macjd_oracle_bench(ctypes.addressof(desc), ctypes.byref(io), int(n_threads), int(n_steps), ctypes.byref(sec))
+    if rc != 0:
+        raise RuntimeError(f"macjd_oracle_bench failed: {rc}")
+    del keep
+    return E * n_steps / sec.value, sec.value
 
 
 def random_actions(rng, E, J, R, with_invalid=True):

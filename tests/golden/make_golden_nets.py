@@ -246,6 +246,46 @@ def gen_nets(out_dir, ref_root):
         rec["t_env_after"] = np.array(runner.t_env)
         np.savez_compressed(os.path.join(out_dir, "episode_e2e.npz"), **rec)
         print("episode_e2e.npz")
+
+        # ---------------- greedy (test_mode=True) episodes of the reference runner: per-step actions + rewards ----------
+        # No torch RNG is consumed in test mode (action_selectors.py:58-60), so a MAC on a HIP device — whose exploration
+        # draws come from the fused kernel's own Philox stream — must reproduce these episodes exactly as well.
+        args = _args(3, 4, 64, episode_limit=100, buffer_size=4)
+        np.random.seed(7); torch.manual_seed(1234)
+        with quiet:
+            env = ElectromagneticEnvironment(args, path)
+            args.env_info = env.get_env_info()
+            mac = BasicMAC(args.obs_shape, args)
+            with torch.no_grad():   # default init gives near-constant Q over time; spread the Q-head so greedy actions vary
+                for p_ in mac.agent.fc2_q_head.parameters():
+                    p_.mul_(4.0)
+            buf = EpisodeReplayBuffer(args)
+            runner = EpisodeRunner(env, mac, buf, args)
+        rec = {"scenario_json": json.dumps(sc), "args_json": json.dumps({k: v for k, v in vars(args).items()
+                                                                         if isinstance(v, (int, float, str, bool))})}
+        rec.update(_sd("agent.", mac.agent.state_dict()))
+        log = []
+        real_step = env.step
+        def logged_step(actions):
+            out = real_step(actions)
+            log.append((np.array([a[0] for a in actions]), np.array([a[1] for a in actions], dtype=np.float64), out[1],
+                        np.array([1 if s_["is_tracking"] else 0 for s_ in out[3]["radar_states"]], dtype=np.uint8)))
+            return out
+        env.step = logged_step
+        with quiet:
+            infos = [runner.run(test_mode=True) for _ in range(2)]
+        for ep, info in enumerate(infos):
+            for k in ("episode_length", "episode_return", "avg_step_reward", "avg_r_d", "avg_r_p", "avg_r_j",
+                      "avg_power_overall", "action_distribution"):
+                rec[f"ep{ep}_{k}"] = np.array(info[k])
+        rec["step_T"] = np.stack([l[0] for l in log]).astype(np.int64)
+        rec["step_P"] = np.stack([l[1] for l in log])
+        rec["step_reward"] = np.array([l[2] for l in log], dtype=np.float64)
+        rec["step_track"] = np.stack([l[3] for l in log])
+        rec["buffer_size_after"] = np.array(buf.current_size)      # test-mode episodes are not stored
+        rec["t_env_after"] = np.array(runner.t_env)
+        np.savez_compressed(os.path.join(out_dir, "episode_greedy.npz"), **rec)
+        print("episode_greedy.npz", "distinct greedy actions:", len(np.unique(rec["step_T"])))
     finally:
         os.chdir(old)
         sys.path.remove(ref_root)

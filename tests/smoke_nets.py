@@ -1,5 +1,6 @@
 """Nets leg of __graft_entry__.smoke(): one tiny MAC action selection + one learner update on cuda:0,
-checked against the NumPy nets oracle (oracle/ is the checker here, never the product path)."""
+checked against the NumPy nets oracle.  Test infrastructure (it imports oracle/): lives under tests/, not in the
+product package."""
 import contextlib
 import io
 import os
@@ -14,8 +15,8 @@ def smoke_nets():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(repo, "oracle"))
     import nets_oracle
-    from .core.mac import BasicMAC
-    from .core.qmix import QMixLearner
+    from macjd_amd.core.mac import BasicMAC
+    from macjd_amd.core.qmix import QMixLearner
     J, R, H = 3, 4, 64
     A, S = 2 * R + 1, 10 * R + 2 * J
     args = SimpleNamespace(n_agents=J, n_actions=A, state_shape=S, obs_shape=S, episode_limit=8, rnn_hidden_dim=H,
