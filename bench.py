@@ -77,9 +77,12 @@ def cpu_baseline(sc, E, seed, budget_s=12.0):
     from _harness import oracle_bench, oracle_lib
     out = {}
     cores_all = max(1, min(oracle_lib().macjd_oracle_max_threads(), os.cpu_count() or 1))
-    try:   # threads the cgroup / affinity mask actually gives this process
+    try:   # threads the affinity mask / cgroup CPU quota actually give this process
         cores_all = max(1, min(cores_all, len(os.sched_getaffinity(0))))
-    except AttributeError:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores_all = max(1, min(cores_all, int(float(quota) / float(period) + 0.5)))
+    except (AttributeError, OSError, ValueError):
         pass
     for label, nt in (("1", 1), ("all", cores_all)):
         n_env = E * nt

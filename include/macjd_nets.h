@@ -343,6 +343,62 @@ typedef struct macjd_grugates_io {
 
 int macjd_gru_gates(const macjd_grugates_io* io, void* hip_stream);
 
+/*
+ * The whole QMix mixer as ONE launch each way (reference core/networks.py:250-315, QMixer.forward):
+ *   s~ = LayerNorm(s)                                                                     networks.py:283
+ *   [h_w1 | h_wf | h_V | b1_raw] = s~ W_first^T + b_first, ReLU on the first 2 Hh + Em columns   (first layers of
+ *                                   hyper_w_1, hyper_w_final, V and the one-layer hyper_b_1, merged: 2 Hh + 2 Em rows)
+ *   w1_raw = h_w1 W2^T + b2 [J Em]    wf_raw = h_wf Wf2^T + bf2 [Em]    v_raw = h_V . wV2 + bV2
+ *   y = ELU(q . clamp(w1_raw,0,5) + clamp(b1_raw,-5,5)) . clamp(wf_raw,0,5) + clamp(v_raw,-5,5)
+ * on the matrix cores in exact float32 (v_mfma_f32_16x16x4_f32).  A workgroup owns 16 rows; its four waves split the
+ * OUTPUT columns of every layer (M = batch x steps is only a few thousand rows: 16-row workgroups fill the chip, and a
+ * row's whole chain stays inside one workgroup).  Weights are read as MFMA operand fragments straight from L2 — every
+ * fragment of the launch is requested before the first arithmetic instruction, so the chain pays one memory latency —
+ * activations pass between the layers through LDS, and the hyper-network outputs w1_raw / wf_raw are consumed from the
+ * accumulators: they are never written to memory (the unfused form materialises w1_raw [M, J Em] in HBM and
+ * contracts it in a second kernel).  Replaces 7 launches of the mixer forward (LayerNorm, 3 library GEMMs, ReLU,
+ * row-dot, tail) by one, for the eval and the target mixer alike.
+ *
+ * Training (save != 0): the forward also stores what the weight-gradient products need — s~, xhat = (s - mean) rstd
+ * and the first-layer output `act` [M, 2 Hh + 2 Em] (post-ReLU blocks, then b1_raw).
+ * Backward (macjd_mixer_fused_backward): re-derives w1_raw / wf_raw / v_raw from `act` (same instruction sequence,
+ * bit-identical), then writes dL/dq [M,J], the output gradients of the second layers (g_w1raw [M,J Em], g_wfraw [M,Em],
+ * g_v [M]) and — through the transposed second-layer weights and the ReLU masks — the output gradient of the merged
+ * first layer `gout1` [M, 2 Hh + 2 Em].  No gradient flows to the state.  The weight / bias / LayerNorm-parameter
+ * gradients are split-K products of these matrices (macjd_linear_wgrad_many, macjd_layernorm_param_grad).
+ *
+ * Supported: hyper_hidden_dim Hh = 128, mixing_embed_dim Em = 64 (the reference's sizes), n_agents J in {2, 3, 6},
+ * state_dim S <= 16 * {2, 3, 6} resp. (the shipped 2j/2r, 3j/4r and 6j/8r scenarios); everything else returns
+ * MACJD_EUNSUPPORTED and the caller keeps the unfused kernels.
+ */
+typedef struct macjd_mixerf_io {
+    int64_t M;                 /* rows */
+    int32_t J, S, Hh, Em;      /* agents, state_dim, hyper_hidden_dim, mixing_embed_dim */
+    int32_t save, reserved;    /* forward: != 0 stores sn / xhat / act */
+    float ln_eps;  float reserved_f;
+    const float* s;   int64_t s_ld;      /* [M,S] state rows */
+    const float* q;            /* [M,J] agent Q-values (contiguous) */
+    const float* ln_w; const float* ln_b;      /* state_norm.{weight,bias} [S] */
+    const float* W1; const float* b1;          /* merged first layer [2Hh+2Em, S] row-major (row stride S), bias [2Hh+2Em]:
+                                                  rows = hyper_w_1.0 | hyper_w_final.0 | V.0 | hyper_b_1 */
+    const float* W2; const float* b2;          /* hyper_w_1.2     [J Em, Hh], [J Em] */
+    const float* Wf2; const float* bf2;        /* hyper_w_final.2 [Em, Hh],  [Em]   */
+    const float* wV2; const float* bV2;        /* V.2             [1, Em],   [1]    */
+    float* y;                  /* [M] Q_tot (forward out) */
+    float* sn; float* xhat;    /* [M,S] contiguous (forward out when save; sn unused by backward) */
+    float* act;                /* [M, 2Hh+2Em] contiguous (forward out when save, backward in) */
+    const float* gy;           /* [M] dL/dy (backward in) */
+    float* gq;                 /* [M,J]        (backward outs) */
+    float* gout1;              /* [M, 2Hh+2Em] */
+    float* g_w1raw;            /* [M, J Em]    */
+    float* g_wfraw;            /* [M, Em]      */
+    float* g_v;                /* [M]          */
+} macjd_mixerf_io;
+
+int macjd_mixer_fused_supported(int32_t J, int32_t S, int32_t Hh, int32_t Em);   /* 1 / 0 */
+int macjd_mixer_fused_forward(const macjd_mixerf_io* io, void* hip_stream);
+int macjd_mixer_fused_backward(const macjd_mixerf_io* io, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,7 @@ EXPORTS = [
     "macjd_qhead_select", "macjd_gru_sequence", "macjd_mixer_tail_forward", "macjd_mixer_tail_backward",
     "macjd_mlp_forward", "macjd_mlp_forward_pair", "macjd_td_loss", "macjd_clip_adam_step", "macjd_gather_rows",
     "macjd_linear_wgrad", "macjd_linear_wgrad_workspace_floats", "macjd_linear_wgrad_many", "macjd_qhead_input", "macjd_layernorm_forward", "macjd_layernorm_param_grad", "macjd_gru_gates", "macjd_rowdot", "macjd_splitrelu_backward",
+    "macjd_mixer_fused_supported", "macjd_mixer_fused_forward", "macjd_mixer_fused_backward",
 ]
 
 
@@ -96,6 +97,21 @@ class MixerIO(ctypes.Structure):
         ("gy", ctypes.c_void_p), ("gq", ctypes.c_void_p), ("gw1_raw", ctypes.c_void_p),
         ("gb1_raw", ctypes.c_void_p), ("gwf_raw", ctypes.c_void_p), ("gv_raw", ctypes.c_void_p),
         ("b1_ld", ctypes.c_int64),
+    ]
+
+
+class MixerFusedIO(ctypes.Structure):
+    """ctypes mirror of ``macjd_mixerf_io`` (include/macjd_nets.h)."""
+    _fields_ = [
+        ("M", ctypes.c_int64), ("J", ctypes.c_int32), ("S", ctypes.c_int32), ("Hh", ctypes.c_int32), ("Em", ctypes.c_int32),
+        ("save", ctypes.c_int32), ("reserved", ctypes.c_int32), ("ln_eps", ctypes.c_float), ("reserved_f", ctypes.c_float),
+        ("s", ctypes.c_void_p), ("s_ld", ctypes.c_int64), ("q", ctypes.c_void_p),
+        ("ln_w", ctypes.c_void_p), ("ln_b", ctypes.c_void_p), ("W1", ctypes.c_void_p), ("b1", ctypes.c_void_p),
+        ("W2", ctypes.c_void_p), ("b2", ctypes.c_void_p), ("Wf2", ctypes.c_void_p), ("bf2", ctypes.c_void_p),
+        ("wV2", ctypes.c_void_p), ("bV2", ctypes.c_void_p),
+        ("y", ctypes.c_void_p), ("sn", ctypes.c_void_p), ("xhat", ctypes.c_void_p), ("act", ctypes.c_void_p),
+        ("gy", ctypes.c_void_p), ("gq", ctypes.c_void_p), ("gout1", ctypes.c_void_p), ("g_w1raw", ctypes.c_void_p),
+        ("g_wfraw", ctypes.c_void_p), ("g_v", ctypes.c_void_p),
     ]
 
 
@@ -251,6 +267,11 @@ def load() -> ctypes.CDLL:
     for name in ("macjd_mixer_tail_forward", "macjd_mixer_tail_backward"):
         getattr(lib, name).restype = ctypes.c_int
         getattr(lib, name).argtypes = [ctypes.POINTER(MixerIO), ctypes.c_void_p]
+    lib.macjd_mixer_fused_supported.restype = ctypes.c_int
+    lib.macjd_mixer_fused_supported.argtypes = [ctypes.c_int32] * 4
+    for name in ("macjd_mixer_fused_forward", "macjd_mixer_fused_backward"):
+        getattr(lib, name).restype = ctypes.c_int
+        getattr(lib, name).argtypes = [ctypes.POINTER(MixerFusedIO), ctypes.c_void_p]
     lib.macjd_qhead_input.restype = ctypes.c_int
     lib.macjd_qhead_input.argtypes = [ctypes.POINTER(QinputIO), ctypes.c_void_p]
     lib.macjd_layernorm_forward.restype = ctypes.c_int

@@ -279,11 +279,44 @@ class QMixer(nn.Module):
             raw = tuple(r.float() for r in raw)
         return raw
 
+    # the whole mixer as one MFMA chain per direction (ops.mixer_fused, csrc/macjd_mixer.hip); off -> LayerNorm + library
+    # GEMMs + the tail kernel (also the path of sizes the fused kernel does not cover and of the bf16 option)
+    fused = os.environ.get("MACJD_FUSED_MIXER", "1") != "0"
+
+    def fused_available(self, t) -> bool:
+        return (self.fused and t.is_cuda and not self.bf16_hyper and not torch.is_autocast_enabled()
+                and ops.mixer_fused_supported(self.n_agents, self.state_dim, self.hyper_hidden_dim, self.embed_dim))
+
+    def _first_layer_cat(self):
+        """(W_cat [2Hh+2Em, S], b_cat) of the merged first layer: the flat-parameter views, the inference cache, or a
+        fresh concatenation."""
+        if self._merged_views is not None:
+            return self._merged_views
+        if self._cat_cache is not None and not torch.is_grad_enabled():
+            return self._cat_cache
+        ps = self.first_layer_params()
+        return torch.cat([p.detach() for p in ps[:4]], dim=0), torch.cat([p.detach() for p in ps[4:]])
+
+    def _forward_fused(self, agent_qs, states):
+        q = agent_qs.reshape(-1, self.n_agents)
+        s = states.reshape(-1, self.state_dim)
+        ln, w_cat_b = self.state_norm, self._first_layer_cat()
+        l2 = (self.hyper_w_1[2].weight, self.hyper_w_1[2].bias, self.hyper_w_final[2].weight, self.hyper_w_final[2].bias,
+              self.V[2].weight, self.V[2].bias)
+        if torch.is_grad_enabled() and (q.requires_grad or ln.weight.requires_grad or l2[0].requires_grad):
+            return ops.mixer_fused(q, s, ln.weight, ln.bias, ln.eps, w_cat_b[0], w_cat_b[1], *l2, self.first_layer_params())
+        params = ops._mixerf_params(ln.weight, ln.bias, ln.eps, w_cat_b[0], w_cat_b[1], *l2)
+        return ops.mixer_fused_forward(q, s, params, save=False)[0]
+
     def forward(self, agent_qs, states, hyper=None):
         """Q_tot = ELU(q . clamp(W1(s),0,5) + clamp(b1(s),-5,5)) . clamp(Wf(s),0,5) + clamp(V(s),-5,5)
         on the LayerNorm-ed state (networks.py:250-315; note clamp, not abs).  Output shape follows
         the reference: [B, T, 1] for [B, T, J] inputs, [B, 1] for [B, J]."""
         batch_size = agent_qs.size(0)
+        if hyper is None and self.fused_available(agent_qs):
+            y = self._forward_fused(agent_qs, states)
+            q_tot = y.view(batch_size, -1, 1)
+            return q_tot.squeeze(1) if q_tot.shape[1] == 1 else q_tot
         raw = hyper if hyper is not None else self.hyper_outputs(states)
         q = agent_qs.reshape(-1, self.n_agents)
         # clamp -> bmm -> ELU -> bmm (+ its backward) is one fused kernel on a HIP device (ops.mixer_tail)

@@ -336,7 +336,9 @@ class QMixLearner:
                 p_eval = body.actor_forward(rows)
             eval_q_tot = eval_forward()
             with torch.no_grad():
-                hyper = self.target_qmix_net.hyper_outputs(st["state"])
+                # unfused mixer: its state-only half (LayerNorm + hyper-networks) runs here, before the join; the fused
+                # mixer is ONE launch that needs the target Q-values, i.e. it runs behind the join
+                hyper = None if self.target_qmix_net.fused_available(st["state"]) else self.target_qmix_net.hyper_outputs(st["state"])
                 origin.wait_stream(ts)                                                          # join
                 for t_ in list(bases) + ([p_target] if p_target is not None else []):
                     t_.record_stream(origin)
@@ -347,7 +349,7 @@ class QMixLearner:
                 bases = scan_chain()
                 p_eval = body.actor_forward(rows)
                 params = [p_eval if shared else macs[0].agent.actor_forward(rows), p_eval]
-                hyper = self.target_qmix_net.hyper_outputs(st["state"])
+                hyper = None if self.target_qmix_net.fused_available(st["state"]) else self.target_qmix_net.hyper_outputs(st["state"])
                 target_q_tot = self.target_qmix_net(double_q(bases, params), st["state"], hyper=hyper)
             eval_q_tot = eval_forward()
         return self._finish_update(st, T, eval_q_tot, target_q_tot)

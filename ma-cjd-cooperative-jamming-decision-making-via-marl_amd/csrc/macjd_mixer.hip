@@ -1,0 +1,433 @@
+// macjd_mixer.hip — the QMix mixer (reference core/networks.py:250-315) as one MFMA chain per direction.
+// C-ABI and the algebra: include/macjd_nets.h (macjd_mixerf_io).
+//
+// Geometry.  M = batch x steps is a few thousand rows (3232 for the reference batch), the widest layer has 384 output
+// columns: tiling the rows 64 at a time (as the agent's dense-chain kernel does for its 10^4..10^5 rows) would leave
+// 4/5 of the chip idle.  Here a workgroup owns 16 rows — ONE MFMA row tile — and its four waves split the output
+// COLUMNS of each layer, so 3232 rows are 202 workgroups of 256 threads and a row's whole chain (LayerNorm, merged
+// first layer, ReLU, both second layers, clamps, the two contractions with q and w_final, ELU) never leaves the
+// workgroup:
+//   phase 0  LayerNorm of the 16 rows (wave w: rows 4w..4w+3, 16 lanes per row)              -> LDS As [16][16 SQ]
+//   phase 1  [16, 384] = As W1^T + b1, ReLU on the first 320 columns; wave w: column tiles 6w..6w+5  -> LDS Hs
+//   phase 2  wave w = embed block e in [16w, 16w+16): the J tiles w1_raw[:, j, e-block] and the tile wf_raw[:, e-block]
+//            stay in accumulators; hid = q . clamp(w1) + clamp(b1), ELU, . clamp(wf): registers; the sum over a row's
+//            16 columns is a 4-step xor shuffle, the sum over the 4 embed blocks goes through 256 B of LDS.
+// Operands.  A (activations) comes from LDS by ds_read_b128 with the permuted-k assignment of macjd_mlp.hip (lane group
+// g supplies k = 16 Q + 4 g + jj in MFMA jj of quad Q: one float4 feeds four MFMAs; pitches = 8 mod 16 floats are
+// conflict-free).  B (weights) is NOT staged: with 16 rows per workgroup a staged image would be read once, so every
+// lane loads its own fragments W[16 t + (lane & 15)][16 Q + 4 g ..+3] straight from L2 (the weights are ~230 KB,
+// shared by all workgroups), and ALL of them are requested at the top of the kernel — they depend on nothing — so the
+// whole chain waits for memory once.  ~200 VGPRs of fragments at 3j/4r; one wave per SIMD has 512.
+// Numerics: v_mfma_f32_16x16x4_f32 is an exact-f32 fmaf chain; the tail uses the same expressions (fmaf chain over the
+// agents starting from clamp(b1), expm1f) as mixer_tail_kernel.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/macjd.h"
+#include "../../include/macjd_nets.h"
+#include "macjd_err.h"
+
+namespace macjd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));   // weight rows are only 4-byte aligned (S = 46)
+
+constexpr int MX_HH = 128, MX_EM = 64;
+constexpr int MX_N1 = 2 * MX_HH + 2 * MX_EM;   // 384 columns of the merged first layer
+constexpr int MX_RELU = 2 * MX_HH + MX_EM;     // the first 320 of them pass a ReLU
+constexpr int MX_LDH = MX_N1 + 8;              // LDS pitch of the first-layer output (= 8 mod 16)
+constexpr int MX_KQ2 = MX_HH / 16;             // quads (16 k each) of the second layers
+
+__device__ __forceinline__ float mx_clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+__device__ __forceinline__ float mx_sum16(float x) {   // sum over the 16 lanes that share lane >> 4
+    x += __shfl_xor(x, 1, 64);
+    x += __shfl_xor(x, 2, 64);
+    x += __shfl_xor(x, 4, 64);
+    x += __shfl_xor(x, 8, 64);
+    return x;
+}
+__device__ __forceinline__ f32x4 mx_mfma4(const f32x4 a, const f32x4 b, f32x4 acc) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], b[jj], acc, 0, 0, 0);
+    return acc;
+}
+
+// B fragments (all quads) of one 16-column tile whose weight rows are `row0 + (lane & 15)` of a row-major [*, K] matrix
+template <int NQ>
+__device__ __forceinline__ void mx_load_frags(f32x4 (&dst)[NQ], const float* __restrict__ W, int64_t K, int row, int g) {
+    const float* p = W + (int64_t)row * K + 4 * g;
+#pragma unroll
+    for (int Q = 0; Q < NQ; ++Q) {
+        const int k0 = 16 * Q + 4 * g;
+        if (k0 + 4 <= K) {
+            dst[Q] = *reinterpret_cast<const f32x4_u*>(p + 16 * Q);
+        } else {   // the ragged end of a row (S = 46): element-wise, zeros past the row
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) dst[Q][jj] = (k0 + jj < K) ? p[16 * Q + jj] : 0.0f;
+        }
+    }
+}
+
+// Second layers + tail for this wave's embed block, shared by the forward kernel and the backward's recomputation:
+// acc2[j] = tile (j, eb) of w1_raw WITHOUT its bias, accf = tile eb of wf_raw without its bias.
+template <int J>
+__device__ __forceinline__ void mx_second_layers(const float* __restrict__ Hs, const f32x4 (&B2)[J][MX_KQ2],
+                                                 const f32x4 (&Bf)[MX_KQ2], f32x4 (&acc2)[J], f32x4& accf, int li, int g) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) acc2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    accf = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* a1p = Hs + li * MX_LDH + 4 * g;            // h_w1: columns [0, Hh)
+    const float* afp = a1p + MX_HH;                         // h_wf: columns [Hh, 2 Hh)
+#pragma unroll
+    for (int Q = 0; Q < MX_KQ2; ++Q) {
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(a1p + 16 * Q);
+        const f32x4 af = *reinterpret_cast<const f32x4*>(afp + 16 * Q);
+#pragma unroll
+        for (int j = 0; j < J; ++j) acc2[j] = mx_mfma4(a1, B2[j][Q], acc2[j]);
+        accf = mx_mfma4(af, Bf[Q], accf);
+    }
+}
+
+// v_raw of row (lane & 15): h_V . wV2 + bV2, valid in the lanes with g == 0 afterwards (every wave may call it)
+__device__ __forceinline__ float mx_v_raw(const float* __restrict__ Hs, const float* __restrict__ wV2, float bV2, int li, int g) {
+    float s = 0.0f;
+    const float* hv = Hs + li * MX_LDH + 2 * MX_HH + 16 * g;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s = fmaf(hv[k], wV2[16 * g + k], s);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    return s + bV2;
+}
+
+template <int J, int SQ>
+__global__ void __launch_bounds__(256) mixer_fused_forward_kernel(const macjd_mixerf_io io) {
+    constexpr int LDA = 16 * SQ + 8;
+    constexpr int T1W = MX_N1 / 16 / 4;   // 6 first-layer column tiles per wave
+    __shared__ __attribute__((aligned(16))) float As[16 * LDA];
+    __shared__ __attribute__((aligned(16))) float Hs[16 * MX_LDH];
+    __shared__ float part[4][16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    const int64_t m0 = (int64_t)blockIdx.x * 16;
+    const int S = io.S;
+
+    // ---- every weight fragment of the launch, requested up front ----
+    f32x4 B1[T1W][SQ], B2[J][MX_KQ2], Bf[MX_KQ2];
+#pragma unroll
+    for (int i = 0; i < T1W; ++i) mx_load_frags<SQ>(B1[i], io.W1, S, 16 * (T1W * wave + i) + li, g);
+#pragma unroll
+    for (int j = 0; j < J; ++j) mx_load_frags<MX_KQ2>(B2[j], io.W2, MX_HH, j * MX_EM + 16 * wave + li, g);
+    mx_load_frags<MX_KQ2>(Bf, io.Wf2, MX_HH, 16 * wave + li, g);
+    // this lane's rows of q (rows 4g..4g+3 of the tile), for the tail
+    float qv[4][J];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t m = m0 + 4 * g + r;
+#pragma unroll
+        for (int j = 0; j < J; ++j) qv[r][j] = (m < io.M) ? io.q[m * J + j] : 0.0f;
+    }
+
+    // ---- phase 0: LayerNorm (networks.py:283), wave w: rows 4w..4w+3, lane (g = row within the wave, li = column mod 16)
+    {
+        const int row = 4 * wave + g;
+        const int64_t m = m0 + row;
+        float x[SQ];
+        float sum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < SQ; ++c) {
+            const int col = li + 16 * c;
+            x[c] = (m < io.M && col < S) ? io.s[m * io.s_ld + col] : 0.0f;
+            sum += x[c];
+        }
+        const float mean = mx_sum16(sum) / (float)S;
+        float sq = 0.0f;
+#pragma unroll
+        for (int c = 0; c < SQ; ++c) {
+            const float d = (li + 16 * c < S) ? x[c] - mean : 0.0f;
+            sq = fmaf(d, d, sq);
+        }
+        const float rstd = rsqrtf(mx_sum16(sq) / (float)S + io.ln_eps);
+#pragma unroll
+        for (int c = 0; c < SQ; ++c) {
+            const int col = li + 16 * c;
+            const bool live = col < S;
+            const float xh = live ? (x[c] - mean) * rstd : 0.0f;
+            const float v = live ? xh * io.ln_w[col] + io.ln_b[col] : 0.0f;   // pad columns: 0 (they meet zero fragments)
+            As[row * LDA + col] = v;
+            if (io.save && live && m < io.M) {
+                io.sn[m * S + col] = v;
+                io.xhat[m * S + col] = xh;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1: merged first layer (networks.py:285-299), this wave's 6 column tiles ----
+    {
+        f32x4 acc[T1W];
+#pragma unroll
+        for (int i = 0; i < T1W; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* ap = As + li * LDA + 4 * g;
+#pragma unroll
+        for (int Q = 0; Q < SQ; ++Q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ap + 16 * Q);
+#pragma unroll
+            for (int i = 0; i < T1W; ++i) acc[i] = mx_mfma4(a, B1[i][Q], acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < T1W; ++i) {
+            const int col = 16 * (T1W * wave + i) + li;
+            const float bias = io.b1[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * g + r;
+                float v = acc[i][r] + bias;
+                v = (col < MX_RELU) ? fmaxf(v, 0.0f) : v;
+                Hs[row * MX_LDH + col] = v;
+                if (io.save && m0 + row < io.M) io.act[(m0 + row) * MX_N1 + col] = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: second layers for embed block `wave`, tail (networks.py:301-310) ----
+    f32x4 acc2[J], accf;
+    mx_second_layers<J>(Hs, B2, Bf, acc2, accf, li, g);
+    const int e = 16 * wave + li;
+    const float bfe = io.bf2[e];
+    float b2e[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) b2e[j] = io.b2[j * MX_EM + e];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r;
+        float hid = mx_clamp(Hs[row * MX_LDH + MX_RELU + e], -5.0f, 5.0f);
+#pragma unroll
+        for (int j = 0; j < J; ++j) hid = fmaf(qv[r][j], mx_clamp(acc2[j][r] + b2e[j], 0.0f, 5.0f), hid);   // bmm(q, w1) + b1
+        const float h = hid > 0.0f ? hid : expm1f(hid);                                                       // F.elu
+        const float t = mx_sum16(h * mx_clamp(accf[r] + bfe, 0.0f, 5.0f));                                    // bmm(hidden, w_final)
+        if (li == 0) part[wave][row] = t;
+    }
+    const float v_raw = (wave == 0) ? mx_v_raw(Hs, io.wV2, io.bV2[0], li, g) : 0.0f;
+    __syncthreads();
+    if (wave == 0 && g == 0) {
+        const int64_t m = m0 + li;
+        if (m < io.M) io.y[m] = ((part[0][li] + part[1][li]) + (part[2][li] + part[3][li])) + mx_clamp(v_raw, -5.0f, 5.0f);
+    }
+}
+
+// Backward (see the header): recompute the second layers from `act`, tail gradients, transposed second layers.
+template <int J>
+__global__ void __launch_bounds__(256) mixer_fused_backward_kernel(const macjd_mixerf_io io) {
+    constexpr int LDG = J * MX_EM + 8;      // pitch of g_w1raw in LDS (= 8 mod 16)
+    constexpr int LDF = MX_EM + 8;
+    constexpr int KQ1 = J * MX_EM / 16;     // quads of the transposed hyper_w_1.2 product
+    constexpr int KQF = MX_EM / 16;
+    __shared__ __attribute__((aligned(16))) float Hs[16 * MX_LDH];
+    __shared__ __attribute__((aligned(16))) float G1[16 * LDG];
+    __shared__ __attribute__((aligned(16))) float Gf[16 * LDF];
+    __shared__ float gq_part[4][16][J];
+    __shared__ float gv_s[16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    const int64_t m0 = (int64_t)blockIdx.x * 16;
+
+    // ---- weight fragments, requested up front: forward orientation for the recomputation ...
+    f32x4 B2[J][MX_KQ2], Bf[MX_KQ2];
+#pragma unroll
+    for (int j = 0; j < J; ++j) mx_load_frags<MX_KQ2>(B2[j], io.W2, MX_HH, j * MX_EM + 16 * wave + li, g);
+    mx_load_frags<MX_KQ2>(Bf, io.Wf2, MX_HH, 16 * wave + li, g);
+    // ... and transposed for the input gradients of the second layers: this wave's output columns are the hidden units
+    // n = 16 (2 wave + tt) + li; B[k][n] = W2[k][n] with k = 16 Q + 4 g + jj the row (a w1_raw column): four strided
+    // dwords per quad, each a coalesced 64-byte row piece over li
+    // (J = 6: both fragment sets together would need more than the 512 registers; the transposed set is then
+    // requested after the recomputation, when the forward set is dead)
+    constexpr bool EARLY_D = (J <= 3);
+    f32x4 D1[2][KQ1], Df[2][KQF];
+    auto load_transposed = [&]() {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int n = 16 * (2 * wave + tt) + li;
+#pragma unroll
+            for (int Q = 0; Q < KQ1; ++Q)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) D1[tt][Q][jj] = io.W2[(int64_t)(16 * Q + 4 * g + jj) * MX_HH + n];
+#pragma unroll
+            for (int Q = 0; Q < KQF; ++Q)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) Df[tt][Q][jj] = io.Wf2[(int64_t)(16 * Q + 4 * g + jj) * MX_HH + n];
+        }
+    };
+    if (EARLY_D) load_transposed();
+    float qv[4][J], gyv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t m = m0 + 4 * g + r;
+        gyv[r] = (m < io.M) ? io.gy[m] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) qv[r][j] = (m < io.M) ? io.q[m * J + j] : 0.0f;
+    }
+    // ---- the saved first-layer output of the 16 rows -> LDS (float4 pieces; rows past M: zeros) ----
+    for (int idx = threadIdx.x; idx < 16 * (MX_N1 / 4); idx += 256) {
+        const int row = idx / (MX_N1 / 4), c4 = idx - row * (MX_N1 / 4);
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (m0 + row < io.M) v = *reinterpret_cast<const f32x4*>(io.act + (m0 + row) * MX_N1 + 4 * c4);
+        *reinterpret_cast<f32x4*>(Hs + row * MX_LDH + 4 * c4) = v;
+    }
+    __syncthreads();
+
+    // ---- recompute w1_raw / wf_raw tiles of embed block `wave` and the tail, then its gradients ----
+    f32x4 acc2[J], accf;
+    mx_second_layers<J>(Hs, B2, Bf, acc2, accf, li, g);
+    const int e = 16 * wave + li;
+    const float bfe = io.bf2[e];
+    float b2e[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) b2e[j] = io.b2[j * MX_EM + e];
+    const float v_raw = (wave == 0) ? mx_v_raw(Hs, io.wV2, io.bV2[0], li, g) : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r;
+        const int64_t m = m0 + row;
+        const float b1r = Hs[row * MX_LDH + MX_RELU + e];
+        float hid = mx_clamp(b1r, -5.0f, 5.0f);
+        float w1r[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            w1r[j] = acc2[j][r] + b2e[j];
+            hid = fmaf(qv[r][j], mx_clamp(w1r[j], 0.0f, 5.0f), hid);
+        }
+        const float h = hid > 0.0f ? hid : expm1f(hid);
+        const float wfr = accf[r] + bfe;
+        const float ghid = gyv[r] * mx_clamp(wfr, 0.0f, 5.0f) * (hid > 0.0f ? 1.0f : h + 1.0f);   // ELU'(x) = elu(x) + 1, x <= 0
+        const float gwf = (wfr >= 0.0f && wfr <= 5.0f) ? gyv[r] * h : 0.0f;                        // clamp passes inside [lo, hi]
+        const float gb1 = (b1r >= -5.0f && b1r <= 5.0f) ? ghid : 0.0f;
+        Gf[row * LDF + e] = gwf;
+        if (m < io.M) {
+            io.g_wfraw[m * MX_EM + e] = gwf;
+            io.gout1[m * MX_N1 + MX_RELU + e] = gb1;
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const float gw = (w1r[j] >= 0.0f && w1r[j] <= 5.0f) ? ghid * qv[r][j] : 0.0f;
+            G1[row * LDG + j * MX_EM + e] = gw;
+            if (m < io.M) io.g_w1raw[m * (J * MX_EM) + j * MX_EM + e] = gw;
+            const float t = mx_sum16(ghid * mx_clamp(w1r[j], 0.0f, 5.0f));
+            if (li == 0) gq_part[wave][row][j] = t;
+        }
+    }
+    if (!EARLY_D) load_transposed();
+    if (wave == 0 && g == 0) {   // v = clamp(v_raw, -5, 5): row li
+        const int64_t m = m0 + li;
+        const float gy_row = (m < io.M) ? io.gy[m] : 0.0f;
+        const float gv = (v_raw >= -5.0f && v_raw <= 5.0f) ? gy_row : 0.0f;
+        gv_s[li] = gv;
+        if (m < io.M) io.g_v[m] = gv;
+    }
+    __syncthreads();
+    // dL/dq: the four embed blocks' partial sums in fixed order
+    for (int idx = threadIdx.x; idx < 16 * J; idx += 256) {
+        const int row = idx / J, j = idx - row * J;
+        if (m0 + row < io.M)
+            io.gq[(m0 + row) * J + j] = (gq_part[0][row][j] + gq_part[1][row][j]) + (gq_part[2][row][j] + gq_part[3][row][j]);
+    }
+
+    // ---- input gradients of the second layers, masked by the first layer's ReLU: columns [0, 2 Hh) of gout1 ----
+    {
+        f32x4 a1[2], af[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) { a1[tt] = f32x4{0.f, 0.f, 0.f, 0.f}; af[tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const float* gp = G1 + li * LDG + 4 * g;
+        const float* fp = Gf + li * LDF + 4 * g;
+#pragma unroll
+        for (int Q = 0; Q < KQ1; ++Q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(gp + 16 * Q);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) a1[tt] = mx_mfma4(a, D1[tt][Q], a1[tt]);
+        }
+#pragma unroll
+        for (int Q = 0; Q < KQF; ++Q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(fp + 16 * Q);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) af[tt] = mx_mfma4(a, Df[tt][Q], af[tt]);
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int n = 16 * (2 * wave + tt) + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * g + r;
+                const int64_t m = m0 + row;
+                if (m < io.M) {
+                    io.gout1[m * MX_N1 + n] = (Hs[row * MX_LDH + n] > 0.0f) ? a1[tt][r] : 0.0f;
+                    io.gout1[m * MX_N1 + MX_HH + n] = (Hs[row * MX_LDH + MX_HH + n] > 0.0f) ? af[tt][r] : 0.0f;
+                }
+            }
+        }
+    }
+    // the V head's one-output second layer: outer product g_v wV2, masked: columns [2 Hh, 2 Hh + Em)
+    for (int idx = threadIdx.x; idx < 16 * MX_EM; idx += 256) {
+        const int row = idx / MX_EM, k = idx - row * MX_EM;
+        if (m0 + row < io.M)
+            io.gout1[(m0 + row) * MX_N1 + 2 * MX_HH + k] = (Hs[row * MX_LDH + 2 * MX_HH + k] > 0.0f) ? gv_s[row] * io.wV2[k] : 0.0f;
+    }
+}
+
+static int mixerf_check(const macjd_mixerf_io* io, bool backward) {
+    if (!io) return set_err(MACJD_EINVAL, "%s", "macjd_mixer_fused: NULL io");
+    if (!macjd_mixer_fused_supported(io->J, io->S, io->Hh, io->Em))
+        return set_err(MACJD_EUNSUPPORTED, "%s", "macjd_mixer_fused: unsupported J / S / Hh / Em (see include/macjd_nets.h)");
+    if (io->M < 0 || !io->q || !io->W2 || !io->b2 || !io->Wf2 || !io->bf2 || !io->wV2 || !io->bV2)
+        return set_err(MACJD_EINVAL, "%s", "macjd_mixer_fused: bad M / NULL input");
+    if (!backward) {
+        if (!io->s || io->s_ld < io->S || !io->ln_w || !io->ln_b || !io->W1 || !io->b1 || !io->y)
+            return set_err(MACJD_EINVAL, "%s", "macjd_mixer_fused_forward: NULL input / output or bad s_ld");
+        if (io->save && (!io->sn || !io->xhat || !io->act))
+            return set_err(MACJD_EINVAL, "%s", "macjd_mixer_fused_forward: save needs sn / xhat / act");
+    } else if (!io->act || !io->gy || !io->gq || !io->gout1 || !io->g_w1raw || !io->g_wfraw || !io->g_v) {
+        return set_err(MACJD_EINVAL, "%s", "macjd_mixer_fused_backward: NULL input / output");
+    }
+    if ((((uintptr_t)io->W2) | ((uintptr_t)io->Wf2) | ((uintptr_t)io->act)) & 15)
+        return set_err(MACJD_EINVAL, "%s", "macjd_mixer_fused: W2 / Wf2 / act must be 16-byte aligned");
+    return MACJD_OK;
+}
+
+}  // namespace macjd
+
+extern "C" int macjd_mixer_fused_supported(int32_t J, int32_t S, int32_t Hh, int32_t Em) {
+    if (Hh != macjd::MX_HH || Em != macjd::MX_EM || S < 1) return 0;
+    return (J == 2 && S <= 32) || (J == 3 && S <= 48) || (J == 6 && S <= 96);
+}
+
+extern "C" int macjd_mixer_fused_forward(const macjd_mixerf_io* io, void* hip_stream) {
+    using namespace macjd;
+    const int rc = mixerf_check(io, false);
+    if (rc != MACJD_OK) return rc;
+    if (io->M == 0) return MACJD_OK;
+    const dim3 grid((unsigned)((io->M + 15) / 16)), block(256);
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (io->J == 2) hipLaunchKernelGGL((mixer_fused_forward_kernel<2, 2>), grid, block, 0, s, *io);
+    else if (io->J == 3) hipLaunchKernelGGL((mixer_fused_forward_kernel<3, 3>), grid, block, 0, s, *io);
+    else hipLaunchKernelGGL((mixer_fused_forward_kernel<6, 6>), grid, block, 0, s, *io);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_mixer_fused_forward: %s", hipGetErrorString(err));
+    return MACJD_OK;
+}
+
+extern "C" int macjd_mixer_fused_backward(const macjd_mixerf_io* io, void* hip_stream) {
+    using namespace macjd;
+    const int rc = mixerf_check(io, true);
+    if (rc != MACJD_OK) return rc;
+    if (io->M == 0) return MACJD_OK;
+    const dim3 grid((unsigned)((io->M + 15) / 16)), block(256);
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (io->J == 2) hipLaunchKernelGGL((mixer_fused_backward_kernel<2>), grid, block, 0, s, *io);
+    else if (io->J == 3) hipLaunchKernelGGL((mixer_fused_backward_kernel<3>), grid, block, 0, s, *io);
+    else hipLaunchKernelGGL((mixer_fused_backward_kernel<6>), grid, block, 0, s, *io);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_mixer_fused_backward: %s", hipGetErrorString(err));
+    return MACJD_OK;
+}

@@ -311,6 +311,128 @@ def mixer_tail(q, w1_raw, b1_raw, wf_raw, v_raw):
     return _MixerTailHip.apply(q, w1_raw, b1_raw, wf_raw, v_raw)
 
 
+# ---------------------------------------------------------------------------------------------
+# The whole mixer as one MFMA chain per direction (csrc/macjd_mixer.hip, include/macjd_nets.h: macjd_mixerf_io)
+def mixer_fused_supported(J: int, S: int, Hh: int, Em: int) -> bool:
+    return bool(_native.load().macjd_mixer_fused_supported(int(J), int(S), int(Hh), int(Em)))
+
+
+def _mixerf_io(q, s, p):
+    """p = dict(ln_w, ln_b, eps, W1, b1, W2, b2, Wf2, bf2, wV2, bV2) of contiguous float32 device tensors."""
+    io = _native.MixerFusedIO()
+    io.M, io.J, io.S, io.Hh, io.Em = q.shape[0], q.shape[1], p["W1"].shape[1], p["W2"].shape[1], p["Wf2"].shape[0]
+    io.ln_eps = float(p["eps"])
+    io.q = q.data_ptr()
+    if s is not None:
+        io.s, io.s_ld = s.data_ptr(), s.stride(0)
+    for k in ("ln_w", "ln_b", "W1", "b1", "W2", "b2", "Wf2", "bf2", "wV2", "bV2"):
+        setattr(io, k, p[k].data_ptr())
+    return io
+
+
+def _mixerf_params(ln_w, ln_b, eps, w_cat, b_cat, W2, b2, Wf2, bf2, wV2, bV2):
+    c = lambda t: t.detach() if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().float().contiguous()
+    return {"ln_w": c(ln_w), "ln_b": c(ln_b), "eps": eps, "W1": c(w_cat), "b1": c(b_cat), "W2": c(W2), "b2": c(b2),
+            "Wf2": c(Wf2), "bf2": c(bf2), "wV2": c(wV2).reshape(-1), "bV2": c(bV2).reshape(-1)}
+
+
+def mixer_fused_forward(q, s, params, save=False):
+    """y [M,1] (+ (sn, xhat, act) when ``save``) of the fused mixer; q [M,J], s [M,S] float32 on a HIP device."""
+    lib = _native.load()
+    q, s = q.detach().float().contiguous(), _f32c(s.detach())
+    M, S = s.shape
+    y = torch.empty((M, 1), dtype=torch.float32, device=q.device)
+    io = _mixerf_io(q, s, params)
+    io.y = y.data_ptr()
+    saved = None
+    if save:
+        width = 2 * io.Hh + 2 * io.Em
+        sn = torch.empty((M, S), dtype=torch.float32, device=q.device)
+        xhat = torch.empty((M, S), dtype=torch.float32, device=q.device)
+        act = torch.empty((M, width), dtype=torch.float32, device=q.device)
+        io.save, io.sn, io.xhat, io.act = 1, sn.data_ptr(), xhat.data_ptr(), act.data_ptr()
+        saved = (sn, xhat, act)
+    with torch.cuda.device(q.device):
+        _native.check(lib.macjd_mixer_fused_forward(ctypes.byref(io), _stream(q)), "macjd_mixer_fused_forward")
+    return y, q, saved
+
+
+class _FusedMixer(torch.autograd.Function):
+    """Q_tot = QMixer(q, s) as one forward and one backward launch (+ the grouped split-K weight gradients).  Inputs:
+    q [M,J] (differentiable), s [M,S] (no gradient), the LayerNorm parameters, the merged first layer (w_cat / b_cat:
+    views of the flat parameter vector or a concatenation; ``first`` = the eight underlying parameters, passed so that
+    autograd routes their gradients: backward returns row blocks of ONE weight-gradient product), the three second
+    layers."""
+
+    @staticmethod
+    def forward(ctx, q, s, ln_w, ln_b, eps, w_cat, b_cat, W2, b2, Wf2, bf2, wV2, bV2, *first):
+        params = _mixerf_params(ln_w, ln_b, eps, w_cat, b_cat, W2, b2, Wf2, bf2, wV2, bV2)
+        y, qc, (sn, xhat, act) = mixer_fused_forward(q, s, params, save=True)
+        ctx.save_for_backward(qc, sn, xhat, act, w_cat, W2, Wf2, wV2, ln_w, ln_b, b2, bf2, bV2)
+        ctx.params = {k: v for k, v in params.items() if k in ("eps",)}
+        ctx.sizes = [p.shape[0] for p in first[:len(first) // 2]]
+        ctx.keys = {"b_cat": grad_key(b_cat), "ln_w": grad_key(ln_w), "ln_b": grad_key(ln_b), "b2": grad_key(b2),
+                    "bf2": grad_key(bf2), "bV2": grad_key(bV2)}
+        ctx.n_first = len(first)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _native.load()
+        q, sn, xhat, act, w_cat, W2, Wf2, wV2, ln_w, ln_b, b2, bf2, bV2 = ctx.saved_tensors
+        M, J = q.shape
+        Hh, Em = W2.shape[1], Wf2.shape[0]
+        dev = q.device
+        gy = gy.detach().float().contiguous()
+        gq = torch.empty((M, J), dtype=torch.float32, device=dev)
+        gout1 = torch.empty((M, 2 * Hh + 2 * Em), dtype=torch.float32, device=dev)
+        g_w1 = torch.empty((M, J * Em), dtype=torch.float32, device=dev)
+        g_wf = torch.empty((M, Em), dtype=torch.float32, device=dev)
+        g_v = torch.empty((M, 1), dtype=torch.float32, device=dev)
+        params = _mixerf_params(ln_w, ln_b, ctx.params["eps"], w_cat, gout1[0], W2, b2, Wf2, bf2, wV2, bV2)   # b1 unused here
+        io = _mixerf_io(q, None, params)
+        io.act, io.gy, io.gq, io.gout1 = act.data_ptr(), gy.data_ptr(), gq.data_ptr(), gout1.data_ptr()
+        io.g_w1raw, io.g_wfraw, io.g_v = g_w1.data_ptr(), g_wf.data_ptr(), g_v.data_ptr()
+        with torch.cuda.device(dev):
+            _native.check(lib.macjd_mixer_fused_backward(ctypes.byref(io), _stream(q)), "macjd_mixer_fused_backward")
+        nd = ctx.needs_input_grad
+        # weight / bias gradients: split-K products of the matrices the kernel wrote (recorded inside deferred_wgrad)
+        gW1, gb1 = linear_wgrad(gout1, sn, want_bias=True, w_key=grad_key(w_cat), b_key=ctx.keys["b_cat"])
+        G, _ = linear_wgrad(gout1, xhat, want_bias=False)
+        gW2, gb2 = linear_wgrad(g_w1, act[:, :Hh], want_bias=True, w_key=grad_key(W2), b_key=ctx.keys["b2"], need=(nd[7], nd[8]))
+        gWf, gbf = linear_wgrad(g_wf, act[:, Hh:2 * Hh], want_bias=True, w_key=grad_key(Wf2), b_key=ctx.keys["bf2"], need=(nd[9], nd[10]))
+        gWv, gbv = linear_wgrad(g_v, act[:, 2 * Hh:2 * Hh + Em], want_bias=True, w_key=grad_key(wV2), b_key=ctx.keys["bV2"],
+                                need=(nd[11], nd[12]))
+        # LayerNorm parameter gradients from (W_cat, G, gb1), one small launch after the grouped products
+        K = w_cat.shape[1]
+        dgamma, dbeta = _grad_dst(ctx.keys["ln_w"], (K,)), _grad_dst(ctx.keys["ln_b"], (K,))
+        if dgamma is None:
+            dgamma = torch.empty(K, dtype=torch.float32, device=dev)
+        if dbeta is None:
+            dbeta = torch.empty(K, dtype=torch.float32, device=dev)
+        lio = _native.LnParamIO()
+        lio.C, lio.K = w_cat.shape[0], K
+        lio.W, lio.w_ld, lio.G, lio.g_ld = w_cat.data_ptr(), w_cat.stride(0), G.data_ptr(), G.stride(0)
+        lio.gb, lio.dgamma, lio.dbeta = gb1.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr()
+        stream = _stream(q)
+
+        def post(lio=lio, keep=(G, w_cat), dev=dev, stream=stream):
+            with torch.cuda.device(dev):
+                _native.check(_native.load().macjd_layernorm_param_grad(ctypes.byref(lio), stream), "macjd_layernorm_param_grad")
+
+        if _DEFERRED_WGRAD is not None:
+            _DEFERRED_POST.append(post)
+        else:
+            post()
+        first = tuple(gW1.split(ctx.sizes, 0)) + tuple(gb1.split(ctx.sizes, 0))
+        return (gq, None, dgamma, dbeta, None, None, None, gW2, gb2, gWf, gbf, gWv, gbv) + first
+
+
+def mixer_fused(q, s, ln_w, ln_b, eps, w_cat, b_cat, W2, b2, Wf2, bf2, wV2, bV2, first_params):
+    """Differentiable fused mixer (see _FusedMixer); y [M, 1]."""
+    return _FusedMixer.apply(q, s, ln_w, ln_b, eps, w_cat, b_cat, W2, b2, Wf2, bf2, wV2, bV2, *first_params)
+
+
 def enable_gemm_tuning(results_file: Optional[str] = None, max_tuning_ms: int = 30) -> bool:
     """Let PyTorch's TunableOp pick the rocBLAS / hipBLASLt solution for each library-GEMM shape on this
     GPU (first call per shape times the candidates).  The path's GEMMs are small and oddly shaped — e.g. the
