@@ -124,33 +124,41 @@ class QMixLearner:
         ``exp_avg`` / ``exp_avg_sq`` entries, here views of the flat vectors), so ``optimizer.pth`` and
         ``load_state_dict`` keep the reference's format (qmix.py:300-315)."""
         tr = self._trainable()
-        flat = torch.cat([p.detach().reshape(-1) for p in tr])
+        # every parameter starts on a 16-byte boundary of the flat vector (float4 / MFMA-fragment loads of the kernels
+        # that read weights in place); the padding elements are zero, get zero gradients and stay zero under Adam.
+        # The merged first layer (4 weights, then 4 biases, all of 16-byte-multiple size at the supported shapes) stays
+        # contiguous: it is read as ONE matrix.
+        self._flat_offsets, off = [], 0
+        for p in tr:
+            self._flat_offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        flat = torch.zeros(off, dtype=tr[0].dtype, device=tr[0].device)
+        for p, o in zip(tr, self._flat_offsets):
+            flat[o:o + p.numel()].copy_(p.detach().reshape(-1))
         self._flat_param = flat
         self._flat_exp_avg = torch.zeros_like(flat)
         self._flat_exp_avg_sq = torch.zeros_like(flat)
         self._adam_step = torch.zeros((), dtype=torch.float32, device=flat.device)
         self._grad_norm = torch.zeros((), dtype=torch.float32, device=flat.device)
         self._adam_partials = torch.zeros(256, dtype=torch.float32, device=flat.device)
-        off = 0
-        for p in tr:
+        for p, off in zip(tr, self._flat_offsets):
             n = p.numel()
             p.data = flat[off:off + n].view_as(p)
             self.optimizer.state[p] = {"step": self._adam_step, "exp_avg": self._flat_exp_avg[off:off + n].view_as(p),
                                        "exp_avg_sq": self._flat_exp_avg_sq[off:off + n].view_as(p)}
-            off += n
         # gradients: ONE flat vector too (the all-reduce buffer); the weight-gradient kernels write their results
         # straight into its slices (ops.deferred_wgrad(grad_dst=...)), so nothing packs the gradients afterwards
         self._flat_grad = torch.zeros_like(flat)
-        self._grad_dst, off = {}, 0
-        for p in tr:
+        self._grad_dst = {}
+        for p, off in zip(tr, self._flat_offsets):
             n = p.numel()
             self._grad_dst[ops.grad_key(p)] = self._flat_grad[off:off + n].view_as(p)
-            off += n
         # merged first layer of the eval mixer = the leading block of the flat vector; the target mixer (inference
         # only) keeps a cached concatenation that its load_state_dict refreshes in place
         mx = self.eval_qmix_net
         first = mx.first_layer_params()
         rows, S = sum(p.shape[0] for p in first[:4]), first[0].shape[1]
+        assert self._flat_offsets[8] == rows * S + rows, "merged first layer must be contiguous in the flat vector"
         mx._merged_views = (flat[:rows * S].view(rows, S), flat[rows * S:rows * S + rows])
         # the merged views alias the first parameter of their block: same address, different size -> different key
         self._grad_dst[ops.grad_key(mx._merged_views[0])] = self._flat_grad[:rows * S].view(rows, S)
@@ -162,8 +170,7 @@ class QMixLearner:
         self.optimizer.load_state_dict(state_dict)
         if self._flat_param is None:
             return
-        off = 0
-        for p in self._trainable():
+        for p, off in zip(self._trainable(), self._flat_offsets):
             n = p.numel()
             st = self.optimizer.state.get(p, {})
             if "exp_avg" in st:
@@ -172,7 +179,6 @@ class QMixLearner:
                 self._adam_step.copy_(torch.as_tensor(st["step"], dtype=torch.float32).reshape(()))
             self.optimizer.state[p] = {"step": self._adam_step, "exp_avg": self._flat_exp_avg[off:off + n].view_as(p),
                                        "exp_avg_sq": self._flat_exp_avg_sq[off:off + n].view_as(p)}
-            off += n
 
     def grad_vector(self):
         """Current gradients of the trainable parameters as one flat vector (a copy unless already flat)."""
@@ -190,21 +196,28 @@ class QMixLearner:
         for p in tr:   # an empty loss (max_seq_len <= 1) reaches nothing: the reference then steps on NaN / None
             if p.grad is None:   # gradients (qmix.py:190-200); here the missing ones count as zero
                 p.grad = torch.zeros_like(p)
-        base, esz, off, in_place = self._flat_grad.data_ptr(), self._flat_grad.element_size(), 0, 0
-        for p in tr:
-            in_place += int(p.grad is not None and p.grad.data_ptr() == base + off * esz and p.grad.is_contiguous())
-            off += p.numel()
+        offs = getattr(self, "_flat_offsets", None)
+        padded = offs is not None
+        if not padded:
+            offs, off = [], 0
+            for p in tr:
+                offs.append(off)
+                off += p.numel()
+        base, esz = self._flat_grad.data_ptr(), self._flat_grad.element_size()
+        in_place = sum(int(p.grad.data_ptr() == base + off * esz and p.grad.is_contiguous()) for p, off in zip(tr, offs))
         if in_place == len(tr):
             return
         self.grad_pack_launches += 1
-        if in_place == 0:
+        if padded:   # 16-byte aligned slots: one small copy per parameter (fallback path only: small batches)
+            packed = [p.grad.reshape(-1).clone() for p in tr]
+            for g_, off in zip(packed, offs):
+                self._flat_grad[off:off + g_.numel()].copy_(g_)
+        elif in_place == 0:
             torch.cat([p.grad.reshape(-1) for p in tr], out=self._flat_grad)
         else:   # some already live in the buffer: pack through a temporary (cat must not read what it overwrites)
             self._flat_grad.copy_(torch.cat([p.grad.reshape(-1) for p in tr]))
-        off = 0
-        for p in tr:
+        for p, off in zip(tr, offs):
             p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
-            off += p.numel()
 
     def _allreduce_grads(self):
         import torch.distributed as dist

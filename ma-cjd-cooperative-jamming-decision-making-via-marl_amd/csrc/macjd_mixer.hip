@@ -33,6 +33,10 @@ namespace macjd {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));   // weight rows are only 4-byte aligned (S = 46)
 
+#ifndef MACJD_MX_ABLATE
+#define MACJD_MX_ABLATE 0   // timing experiments only (results wrong when non-zero): 1 no fragment loads, 2 no phase-1
+#endif                      // MFMAs, 4 no phase-2 MFMAs, 8 no state loads, 16 no tail math
+constexpr int MX_ABL = MACJD_MX_ABLATE;
 constexpr int MX_HH = 128, MX_EM = 64;
 constexpr int MX_N1 = 2 * MX_HH + 2 * MX_EM;   // 384 columns of the merged first layer
 constexpr int MX_RELU = 2 * MX_HH + MX_EM;     // the first 320 of them pass a ReLU
@@ -47,24 +51,29 @@ __device__ __forceinline__ float mx_sum16(float x) {   // sum over the 16 lanes 
     x += __shfl_xor(x, 8, 64);
     return x;
 }
-__device__ __forceinline__ f32x4 mx_mfma4(const f32x4 a, const f32x4 b, f32x4 acc) {
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], b[jj], acc, 0, 0, 0);
-    return acc;
-}
 
-// B fragments (all quads) of one 16-column tile whose weight rows are `row0 + (lane & 15)` of a row-major [*, K] matrix
-template <int NQ>
-__device__ __forceinline__ void mx_load_frags(f32x4 (&dst)[NQ], const float* __restrict__ W, int64_t K, int row, int g) {
-    const float* p = W + (int64_t)row * K + 4 * g;
+// B fragments (all quads) of one 16-column tile whose weight row is `row` of a row-major [*, K] matrix.  No branch
+// around any load: a divergent `if` with a load inside makes hipcc drain the memory counter (s_waitcnt vmcnt(0)) at
+// every join, which serialised the ~50 fragment loads of a wave one L2 latency after the other (16 us per launch
+// instead of ~5).  RAGGED (K not a multiple of 16, e.g. S = 46): the last quad is four dword loads from clamped
+// addresses, zeroed past the row by selects.
+template <int NQ, bool RAGGED>
+__device__ __forceinline__ void mx_load_frags(f32x4 (&dst)[NQ], const float* __restrict__ W, int K, int row, int g) {
+    const float* p = W + (int64_t)row * K;
 #pragma unroll
     for (int Q = 0; Q < NQ; ++Q) {
         const int k0 = 16 * Q + 4 * g;
-        if (k0 + 4 <= K) {
-            dst[Q] = *reinterpret_cast<const f32x4_u*>(p + 16 * Q);
-        } else {   // the ragged end of a row (S = 46): element-wise, zeros past the row
+        if (MX_ABL & 1) {
+            dst[Q] = f32x4{(float)row, (float)g, 1.0f, 0.5f};
+        } else if (!RAGGED || Q < NQ - 1) {   // compile-time
+            dst[Q] = *reinterpret_cast<const f32x4_u*>(p + k0);
+        } else {
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) dst[Q][jj] = (k0 + jj < K) ? p[16 * Q + jj] : 0.0f;
+            for (int jj = 0; jj < 4; ++jj) {
+                const int k = k0 + jj;
+                const float v = p[k < K ? k : K - 1];
+                dst[Q][jj] = (k < K) ? v : 0.0f;
+            }
         }
     }
 }
@@ -80,27 +89,32 @@ __device__ __forceinline__ void mx_second_layers(const float* __restrict__ Hs, c
     const float* a1p = Hs + li * MX_LDH + 4 * g;            // h_w1: columns [0, Hh)
     const float* afp = a1p + MX_HH;                         // h_wf: columns [Hh, 2 Hh)
 #pragma unroll
-    for (int Q = 0; Q < MX_KQ2; ++Q) {
+    for (int Q = 0; Q < ((MX_ABL & 4) ? 0 : MX_KQ2); ++Q) {
         const f32x4 a1 = *reinterpret_cast<const f32x4*>(a1p + 16 * Q);
         const f32x4 af = *reinterpret_cast<const f32x4*>(afp + 16 * Q);
+        // k-step outer, tiles inner: consecutive MFMAs go to different accumulators (a dependent one waits 40 cycles,
+        // the issue interval is 32)
 #pragma unroll
-        for (int j = 0; j < J; ++j) acc2[j] = mx_mfma4(a1, B2[j][Q], acc2[j]);
-        accf = mx_mfma4(af, Bf[Q], accf);
+        for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+            for (int j = 0; j < J; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[jj], B2[j][Q][jj], acc2[j], 0, 0, 0);
+            accf = __builtin_amdgcn_mfma_f32_16x16x4f32(af[jj], Bf[Q][jj], accf, 0, 0, 0);
+        }
     }
 }
 
 // v_raw of row (lane & 15): h_V . wV2 + bV2, valid in the lanes with g == 0 afterwards (every wave may call it)
-__device__ __forceinline__ float mx_v_raw(const float* __restrict__ Hs, const float* __restrict__ wV2, float bV2, int li, int g) {
-    float s = 0.0f;
+__device__ __forceinline__ float mx_v_raw(const float* __restrict__ Hs, const float (&wv)[16], float bV2, int li, int g) {
+    float s = 0.0f;   // wv[k] = wV2[16 g + k], preloaded
     const float* hv = Hs + li * MX_LDH + 2 * MX_HH + 16 * g;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) s = fmaf(hv[k], wV2[16 * g + k], s);
+    for (int k = 0; k < 16; ++k) s = fmaf(hv[k], wv[k], s);
     s += __shfl_xor(s, 16, 64);
     s += __shfl_xor(s, 32, 64);
     return s + bV2;
 }
 
-template <int J, int SQ>
+template <int J, int SQ, bool SAVE>
 __global__ void __launch_bounds__(256) mixer_fused_forward_kernel(const macjd_mixerf_io io) {
     constexpr int LDA = 16 * SQ + 8;
     constexpr int T1W = MX_N1 / 16 / 4;   // 6 first-layer column tiles per wave
@@ -113,32 +127,54 @@ __global__ void __launch_bounds__(256) mixer_fused_forward_kernel(const macjd_mi
     const int64_t m0 = (int64_t)blockIdx.x * 16;
     const int S = io.S;
 
-    // ---- every weight fragment of the launch, requested up front ----
+    // ---- loads, oldest first = needed first (s_waitcnt counts in issue order): the state rows of the LayerNorm, then
+    // every weight fragment of the launch; nothing below depends on anything but kernel arguments ----
+    // (the bias / LayerNorm / V-head vectors too: a load next to its use sits behind the s_waitcnt vmcnt(0) that hipcc
+    // puts at every divergent join, i.e. each one would cost a full memory latency AND drain the fragment loads)
+    float x[SQ], lnw[SQ], lnb[SQ];
+    {
+        const int64_t m = m0 + 4 * wave + g;
+#pragma unroll
+        for (int c = 0; c < SQ; ++c) {
+            const int col = li + 16 * c, cc = col < S ? col : S - 1;
+            x[c] = (MX_ABL & 8) ? (float)col : io.s[(m < io.M ? m : io.M - 1) * io.s_ld + cc];
+            lnw[c] = io.ln_w[cc];
+            lnb[c] = io.ln_b[cc];
+        }
+    }
+    float b1v[T1W], b2e[J], wv[16];
+#pragma unroll
+    for (int i = 0; i < T1W; ++i) b1v[i] = io.b1[16 * (T1W * wave + i) + li];
+#pragma unroll
+    for (int j = 0; j < J; ++j) b2e[j] = io.b2[j * MX_EM + 16 * wave + li];
+    const float bfe = io.bf2[16 * wave + li];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wv[k] = io.wV2[16 * g + k];
+    const float bV2 = io.bV2[0];
     f32x4 B1[T1W][SQ], B2[J][MX_KQ2], Bf[MX_KQ2];
 #pragma unroll
-    for (int i = 0; i < T1W; ++i) mx_load_frags<SQ>(B1[i], io.W1, S, 16 * (T1W * wave + i) + li, g);
+    for (int i = 0; i < T1W; ++i) mx_load_frags<SQ, true>(B1[i], io.W1, S, 16 * (T1W * wave + i) + li, g);
 #pragma unroll
-    for (int j = 0; j < J; ++j) mx_load_frags<MX_KQ2>(B2[j], io.W2, MX_HH, j * MX_EM + 16 * wave + li, g);
-    mx_load_frags<MX_KQ2>(Bf, io.Wf2, MX_HH, 16 * wave + li, g);
+    for (int j = 0; j < J; ++j) mx_load_frags<MX_KQ2, false>(B2[j], io.W2, MX_HH, j * MX_EM + 16 * wave + li, g);
+    mx_load_frags<MX_KQ2, false>(Bf, io.Wf2, MX_HH, 16 * wave + li, g);
     // this lane's rows of q (rows 4g..4g+3 of the tile), for the tail
     float qv[4][J];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int64_t m = m0 + 4 * g + r;
+        const int64_t mc = m < io.M ? m : io.M - 1;   // clamped: rows past M are computed on the last row, never stored
 #pragma unroll
-        for (int j = 0; j < J; ++j) qv[r][j] = (m < io.M) ? io.q[m * J + j] : 0.0f;
+        for (int j = 0; j < J; ++j) qv[r][j] = io.q[mc * J + j];
     }
 
     // ---- phase 0: LayerNorm (networks.py:283), wave w: rows 4w..4w+3, lane (g = row within the wave, li = column mod 16)
     {
         const int row = 4 * wave + g;
         const int64_t m = m0 + row;
-        float x[SQ];
         float sum = 0.0f;
 #pragma unroll
         for (int c = 0; c < SQ; ++c) {
-            const int col = li + 16 * c;
-            x[c] = (m < io.M && col < S) ? io.s[m * io.s_ld + col] : 0.0f;
+            x[c] = (li + 16 * c < S) ? x[c] : 0.0f;
             sum += x[c];
         }
         const float mean = mx_sum16(sum) / (float)S;
@@ -154,9 +190,9 @@ __global__ void __launch_bounds__(256) mixer_fused_forward_kernel(const macjd_mi
             const int col = li + 16 * c;
             const bool live = col < S;
             const float xh = live ? (x[c] - mean) * rstd : 0.0f;
-            const float v = live ? xh * io.ln_w[col] + io.ln_b[col] : 0.0f;   // pad columns: 0 (they meet zero fragments)
+            const float v = live ? xh * lnw[c] + lnb[c] : 0.0f;               // pad columns: 0 (they meet zero fragments)
             As[row * LDA + col] = v;
-            if (io.save && live && m < io.M) {
+            if (SAVE && live && m < io.M) {
                 io.sn[m * S + col] = v;
                 io.xhat[m * S + col] = xh;
             }
@@ -171,22 +207,23 @@ __global__ void __launch_bounds__(256) mixer_fused_forward_kernel(const macjd_mi
         for (int i = 0; i < T1W; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* ap = As + li * LDA + 4 * g;
 #pragma unroll
-        for (int Q = 0; Q < SQ; ++Q) {
+        for (int Q = 0; Q < ((MX_ABL & 2) ? 0 : SQ); ++Q) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(ap + 16 * Q);
 #pragma unroll
-            for (int i = 0; i < T1W; ++i) acc[i] = mx_mfma4(a, B1[i][Q], acc[i]);
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int i = 0; i < T1W; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], B1[i][Q][jj], acc[i], 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < T1W; ++i) {
             const int col = 16 * (T1W * wave + i) + li;
-            const float bias = io.b1[col];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 4 * g + r;
-                float v = acc[i][r] + bias;
+                float v = acc[i][r] + b1v[i];
                 v = (col < MX_RELU) ? fmaxf(v, 0.0f) : v;
                 Hs[row * MX_LDH + col] = v;
-                if (io.save && m0 + row < io.M) io.act[(m0 + row) * MX_N1 + col] = v;
+                if (SAVE && m0 + row < io.M) io.act[(m0 + row) * MX_N1 + col] = v;
             }
         }
     }
@@ -196,10 +233,6 @@ __global__ void __launch_bounds__(256) mixer_fused_forward_kernel(const macjd_mi
     f32x4 acc2[J], accf;
     mx_second_layers<J>(Hs, B2, Bf, acc2, accf, li, g);
     const int e = 16 * wave + li;
-    const float bfe = io.bf2[e];
-    float b2e[J];
-#pragma unroll
-    for (int j = 0; j < J; ++j) b2e[j] = io.b2[j * MX_EM + e];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = 4 * g + r;
@@ -210,7 +243,7 @@ __global__ void __launch_bounds__(256) mixer_fused_forward_kernel(const macjd_mi
         const float t = mx_sum16(h * mx_clamp(accf[r] + bfe, 0.0f, 5.0f));                                    // bmm(hidden, w_final)
         if (li == 0) part[wave][row] = t;
     }
-    const float v_raw = (wave == 0) ? mx_v_raw(Hs, io.wV2, io.bV2[0], li, g) : 0.0f;
+    const float v_raw = (wave == 0) ? mx_v_raw(Hs, wv, bV2, li, g) : 0.0f;
     __syncthreads();
     if (wave == 0 && g == 0) {
         const int64_t m = m0 + li;
@@ -238,8 +271,8 @@ __global__ void __launch_bounds__(256) mixer_fused_backward_kernel(const macjd_m
     // ---- weight fragments, requested up front: forward orientation for the recomputation ...
     f32x4 B2[J][MX_KQ2], Bf[MX_KQ2];
 #pragma unroll
-    for (int j = 0; j < J; ++j) mx_load_frags<MX_KQ2>(B2[j], io.W2, MX_HH, j * MX_EM + 16 * wave + li, g);
-    mx_load_frags<MX_KQ2>(Bf, io.Wf2, MX_HH, 16 * wave + li, g);
+    for (int j = 0; j < J; ++j) mx_load_frags<MX_KQ2, false>(B2[j], io.W2, MX_HH, j * MX_EM + 16 * wave + li, g);
+    mx_load_frags<MX_KQ2, false>(Bf, io.Wf2, MX_HH, 16 * wave + li, g);
     // ... and transposed for the input gradients of the second layers: this wave's output columns are the hidden units
     // n = 16 (2 wave + tt) + li; B[k][n] = W2[k][n] with k = 16 Q + 4 g + jj the row (a w1_raw column): four strided
     // dwords per quad, each a coalesced 64-byte row piece over li
@@ -262,20 +295,30 @@ __global__ void __launch_bounds__(256) mixer_fused_backward_kernel(const macjd_m
         }
     };
     if (EARLY_D) load_transposed();
+    float b2e[J], wv[16], wvo[4];
+#pragma unroll
+    for (int j = 0; j < J; ++j) b2e[j] = io.b2[j * MX_EM + 16 * wave + li];
+    const float bfe = io.bf2[16 * wave + li];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wv[k] = io.wV2[16 * g + k];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wvo[i] = io.wV2[(threadIdx.x + 256 * i) & (MX_EM - 1)];   // for the V head's outer product
+    const float bV2 = io.bV2[0];
+    const float gy_li = io.gy[(m0 + li < io.M) ? m0 + li : io.M - 1];
     float qv[4][J], gyv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int64_t m = m0 + 4 * g + r;
-        gyv[r] = (m < io.M) ? io.gy[m] : 0.0f;
+        const int64_t mc = m < io.M ? m : io.M - 1;   // clamped (no branch around a load); rows past M are never stored
+        gyv[r] = io.gy[mc];
 #pragma unroll
-        for (int j = 0; j < J; ++j) qv[r][j] = (m < io.M) ? io.q[m * J + j] : 0.0f;
+        for (int j = 0; j < J; ++j) qv[r][j] = io.q[mc * J + j];
     }
     // ---- the saved first-layer output of the 16 rows -> LDS (float4 pieces; rows past M: zeros) ----
     for (int idx = threadIdx.x; idx < 16 * (MX_N1 / 4); idx += 256) {
         const int row = idx / (MX_N1 / 4), c4 = idx - row * (MX_N1 / 4);
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (m0 + row < io.M) v = *reinterpret_cast<const f32x4*>(io.act + (m0 + row) * MX_N1 + 4 * c4);
-        *reinterpret_cast<f32x4*>(Hs + row * MX_LDH + 4 * c4) = v;
+        const int64_t mc = (m0 + row < io.M) ? m0 + row : io.M - 1;
+        *reinterpret_cast<f32x4*>(Hs + row * MX_LDH + 4 * c4) = *reinterpret_cast<const f32x4*>(io.act + mc * MX_N1 + 4 * c4);
     }
     __syncthreads();
 
@@ -283,11 +326,7 @@ __global__ void __launch_bounds__(256) mixer_fused_backward_kernel(const macjd_m
     f32x4 acc2[J], accf;
     mx_second_layers<J>(Hs, B2, Bf, acc2, accf, li, g);
     const int e = 16 * wave + li;
-    const float bfe = io.bf2[e];
-    float b2e[J];
-#pragma unroll
-    for (int j = 0; j < J; ++j) b2e[j] = io.b2[j * MX_EM + e];
-    const float v_raw = (wave == 0) ? mx_v_raw(Hs, io.wV2, io.bV2[0], li, g) : 0.0f;
+    const float v_raw = (wave == 0) ? mx_v_raw(Hs, wv, bV2, li, g) : 0.0f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = 4 * g + r;
@@ -322,8 +361,7 @@ __global__ void __launch_bounds__(256) mixer_fused_backward_kernel(const macjd_m
     if (!EARLY_D) load_transposed();
     if (wave == 0 && g == 0) {   // v = clamp(v_raw, -5, 5): row li
         const int64_t m = m0 + li;
-        const float gy_row = (m < io.M) ? io.gy[m] : 0.0f;
-        const float gv = (v_raw >= -5.0f && v_raw <= 5.0f) ? gy_row : 0.0f;
+        const float gv = (v_raw >= -5.0f && v_raw <= 5.0f) ? gy_li : 0.0f;
         gv_s[li] = gv;
         if (m < io.M) io.g_v[m] = gv;
     }
@@ -346,13 +384,17 @@ __global__ void __launch_bounds__(256) mixer_fused_backward_kernel(const macjd_m
         for (int Q = 0; Q < KQ1; ++Q) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(gp + 16 * Q);
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) a1[tt] = mx_mfma4(a, D1[tt][Q], a1[tt]);
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) a1[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], D1[tt][Q][jj], a1[tt], 0, 0, 0);
         }
 #pragma unroll
         for (int Q = 0; Q < KQF; ++Q) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(fp + 16 * Q);
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) af[tt] = mx_mfma4(a, Df[tt][Q], af[tt]);
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) af[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], Df[tt][Q][jj], af[tt], 0, 0, 0);
         }
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
@@ -369,10 +411,12 @@ __global__ void __launch_bounds__(256) mixer_fused_backward_kernel(const macjd_m
         }
     }
     // the V head's one-output second layer: outer product g_v wV2, masked: columns [2 Hh, 2 Hh + Em)
-    for (int idx = threadIdx.x; idx < 16 * MX_EM; idx += 256) {
+#pragma unroll
+    for (int i = 0; i < 16 * MX_EM / 256; ++i) {
+        const int idx = threadIdx.x + 256 * i;
         const int row = idx / MX_EM, k = idx - row * MX_EM;
         if (m0 + row < io.M)
-            io.gout1[(m0 + row) * MX_N1 + 2 * MX_HH + k] = (Hs[row * MX_LDH + 2 * MX_HH + k] > 0.0f) ? gv_s[row] * io.wV2[k] : 0.0f;
+            io.gout1[(m0 + row) * MX_N1 + 2 * MX_HH + k] = (Hs[row * MX_LDH + 2 * MX_HH + k] > 0.0f) ? gv_s[row] * wvo[i] : 0.0f;
     }
 }
 
@@ -390,8 +434,8 @@ static int mixerf_check(const macjd_mixerf_io* io, bool backward) {
     } else if (!io->act || !io->gy || !io->gq || !io->gout1 || !io->g_w1raw || !io->g_wfraw || !io->g_v) {
         return set_err(MACJD_EINVAL, "%s", "macjd_mixer_fused_backward: NULL input / output");
     }
-    if ((((uintptr_t)io->W2) | ((uintptr_t)io->Wf2) | ((uintptr_t)io->act)) & 15)
-        return set_err(MACJD_EINVAL, "%s", "macjd_mixer_fused: W2 / Wf2 / act must be 16-byte aligned");
+    if (((uintptr_t)io->act) & 15)   // (weights may sit anywhere in a flat parameter vector: their fragment loads assume 4 bytes)
+        return set_err(MACJD_EINVAL, "%s", "macjd_mixer_fused: act must be 16-byte aligned");
     return MACJD_OK;
 }
 
@@ -409,9 +453,15 @@ extern "C" int macjd_mixer_fused_forward(const macjd_mixerf_io* io, void* hip_st
     if (io->M == 0) return MACJD_OK;
     const dim3 grid((unsigned)((io->M + 15) / 16)), block(256);
     hipStream_t s = (hipStream_t)hip_stream;
-    if (io->J == 2) hipLaunchKernelGGL((mixer_fused_forward_kernel<2, 2>), grid, block, 0, s, *io);
-    else if (io->J == 3) hipLaunchKernelGGL((mixer_fused_forward_kernel<3, 3>), grid, block, 0, s, *io);
-    else hipLaunchKernelGGL((mixer_fused_forward_kernel<6, 6>), grid, block, 0, s, *io);
+#define MACJD_MXF(J_, SQ_)                                                                                     \
+    do {                                                                                                       \
+        if (io->save) hipLaunchKernelGGL((mixer_fused_forward_kernel<J_, SQ_, true>), grid, block, 0, s, *io);  \
+        else hipLaunchKernelGGL((mixer_fused_forward_kernel<J_, SQ_, false>), grid, block, 0, s, *io);          \
+    } while (0)
+    if (io->J == 2) MACJD_MXF(2, 2);
+    else if (io->J == 3) MACJD_MXF(3, 3);
+    else MACJD_MXF(6, 6);
+#undef MACJD_MXF
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_mixer_fused_forward: %s", hipGetErrorString(err));
     return MACJD_OK;
