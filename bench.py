@@ -260,7 +260,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(J, R, E, args.per_env)[0],
                 "traffic_source": pmc_traffic(J, R, E, args.per_env)[1],
                 "kernel": (f"env_step_kernel<{J},{R},per-env tables>" if args.per_env else
-                           f"env_step_slots_kernel<{J},{R}>" if E < (1 << 17) else f"env_step_kernel<{J},{R}>"),
+                           f"env_step_slots_kernel<{J},{R}>" if E < (1 << 16) else f"env_step_kernel<{J},{R}>"),
                 "us_per_launch": round(ms * 1e3, 3),
                 "timing": "HIP events around 200 launches replayed from one HIP graph on their own stream (macjd_env_step_timed); "
                           "the rocprofv3 kernel-trace average of the same replay is committed under profiles/ (r02_bench_env_roofline_*)",

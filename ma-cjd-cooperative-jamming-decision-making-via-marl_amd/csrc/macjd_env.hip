@@ -848,9 +848,9 @@ static int launch_step(const macjd_scenario* s, const macjd_step_io* io, hipStre
     const int64_t E = io->n_envs;
     const int J = s->host.J, R = s->host.R;
     const bool has_slot_kernel = (J == 3 && R == 4) || (J == 6 && R == 8) || (J == 12 && R == 16) || (J == 2 && R == 2);
-    // measured crossover on MI355X (3j/4r, round 1): slot kernel 4.4 / 8.0 / 24.9 us vs lane kernel 9.2 / 10.1 /
-    // 21.8 us at E = 2^12 / 2^16 / 2^18
-    bool slot_kernel = has_slot_kernel && E < (1 << 17);
+    // measured crossover on MI355X (3j/4r, round 2): slot kernel 3.9 / 4.2 / 7.3 / 21.8 us vs lane kernel 5.6 / 5.7 /
+    // 7.5 / 13.5 us at E = 2^12 / 2^14 / 2^16 / 2^18
+    bool slot_kernel = has_slot_kernel && E < (1 << 16);
     if (io->flags & MACJD_STEP_LANE_KERNEL) slot_kernel = false;
     if ((io->flags & MACJD_STEP_SLOT_KERNEL) && has_slot_kernel) slot_kernel = true;
     const bool per_env = io->pe_tables != nullptr;

@@ -16,9 +16,11 @@ import statistics
 import sys
 
 out, tag = sys.argv[1], sys.argv[2]
-J, R, B_ALG = 3, 4, 85
+per_env = len(sys.argv) > 3 and sys.argv[3] == "per-env"
+J, R = 3, 4
+B_ALG = 85 + ((8 * (6 * R + 3 * J + J * R) + J * R) if per_env else 0)   # bench.py: algorithmic bytes per env-step
 runs = {}
-for E, kern in ((4096, "env_step_slots_kernel"), (4194304, "env_step_kernel")):
+for E, kern in ((4096, "env_step_kernel" if per_env else "env_step_slots_kernel"), (4194304, "env_step_kernel")):
     rec = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         files = glob.glob(os.path.join(out, f"E{E}_{ctr}", "**", "*counter_collection.csv"), recursive=True)
@@ -37,11 +39,12 @@ for E, kern in ((4096, "env_step_slots_kernel"), (4194304, "env_step_kernel")):
         rec["kernel_name"] = kern
         runs[str(E)] = rec
 print(json.dumps({
-    "round": tag, "kernel": f"macjd::env_step_slots_kernel<{J},{R}>",
-    "workload": f"{J} jammers / {R} radars, Philox in-kernel, info outputs on",
+    "round": tag, "kernel": f"macjd::env_step_kernel<{J},{R},per-env>" if per_env else f"macjd::env_step_slots_kernel<{J},{R}>",
+    "workload": f"{J} jammers / {R} radars, Philox in-kernel, info outputs on" + (", per-env scenario tables" if per_env else ""),
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (python3 bench.py --mode env --batch-envs E "
               "--steps 30 --warmup 5); per-dispatch medians; unit KB; gfx950 correction per MI355X_MICROARCH.md section HBM: "
               "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 (scripts/pmc_env_summary.py)",
     "bytes_per_env_step_algorithmic": B_ALG,
-    "note": "E = 4096: (env x slot) kernel; E = 2^22: lane-per-env kernel (the default from 2^17 envs)",
+    "note": ("lane-per-env kernel streaming its env's table column" if per_env else
+             "E = 4096: (env x slot) kernel; E = 2^22: lane-per-env kernel (the default from 2^16 envs)"),
     "runs": runs}, indent=1))
