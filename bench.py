@@ -33,13 +33,15 @@ def per_env_table_bytes(J, R):
 
 def algorithmic_bytes_per_env_step(J, R, uniforms_supplied, info_outputs=True):
     """DESIGN.md section 'Algorithmic bytes': what one env-step must move through HBM.
-    reads : T 4J + P 4J + step 4 (+ uniforms, counted as SURVEY.md 8(d) does, 4(R+J), when supplied)
+    reads : T 4J + P 4J + step 4 + (uniforms, counted as SURVEY.md 8(d) does, 4(R+J), when supplied | episode index 4)
     writes: reward 4 + (r_d,r_p,r_j) 12 + terminated 1 + track R + step 4 (+ pd 4R + snr_with 4R info)
     The FSM's next state does not depend on the previous one (core/radar.py:102-117), so `track` is
     written, never read."""
     b = 4 * J + 4 * J + 4 + 4 + 12 + 1 + R + 4
     if uniforms_supplied:
         b += 4 * (R + J)
+    else:
+        b += 4   # the env's episode index (int32), part of the in-kernel generator's counter
     if info_outputs:
         b += 8 * R
     return b

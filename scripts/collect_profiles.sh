@@ -29,18 +29,26 @@ stats rollout --mode rollout --steps 300 --warmup 100 --no-cpu-baseline --no-oth
 stats train --mode train --steps 300 --warmup 100 --no-cpu-baseline --no-other-modes
 stats env_per_env --mode env --per-env-scenarios --steps 1 --warmup 0 --no-cpu-baseline --no-other-modes
 # (2) PMC passes, one counter per pass (FETCH_SIZE and WRITE_SIZE do not fit one pass), shared and per-env tables
-for PE in "" "--per-env-scenarios"; do
-  D=$OUT/pmc${PE:+_pe}
-  rm -rf $D
-  for E in 4096 4194304; do
-    for C in FETCH_SIZE WRITE_SIZE; do
-      timeout -k 10 300 rocprofv3 --pmc $C -d $D/E${E}_$C -o p --output-format csv -- python3 $ROOT/bench.py --mode env $PE --batch-envs $E --steps 30 --warmup 5 --no-cpu-baseline --no-other-modes > /dev/null 2>&1
-    done
+D=$OUT/pmc
+rm -rf $D
+for E in 4096 4194304; do
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 300 rocprofv3 --pmc $C -d $D/E${E}_$C -o p --output-format csv -- python3 $ROOT/bench.py --mode env --batch-envs $E --steps 30 --warmup 5 --no-cpu-baseline --no-other-modes > /dev/null 2>&1
+    echo "[collect] pmc E=$E $C"
   done
-  python3 $ROOT/scripts/pmc_env_summary.py $D $TAG ${PE:+per-env} > $OUT/${TAG}_env_step${PE:+_per_env}_pmc.json
-  rm -rf $D
-  echo "[collect] pmc${PE:+ per-env} done"
 done
+python3 $ROOT/scripts/pmc_env_summary.py $D $TAG > $OUT/${TAG}_env_step_pmc.json
+rm -rf $D
+# per-env tables: ONE pass per counter at the default E = 4096; the 2^22-env launches come from bench.py's large_batch
+# section (it tiles the 4096 compiled scenarios; compiling 4 M scenarios on the host would take minutes)
+D=$OUT/pmc_pe
+rm -rf $D
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 300 rocprofv3 --pmc $C -d $D/ALL_$C -o p --output-format csv -- python3 $ROOT/bench.py --mode env --per-env-scenarios --steps 30 --warmup 5 --no-cpu-baseline --no-other-modes > /dev/null 2>&1
+  echo "[collect] pmc per-env $C"
+done
+python3 $ROOT/scripts/pmc_env_summary.py $D $TAG per-env > $OUT/${TAG}_env_step_per_env_pmc.json
+rm -rf $D
 # (3) the default bench line (train mode, other modes, CPU baseline)
 cd $ROOT
 timeout -k 10 500 python3 bench.py 2> $OUT/${TAG}_bench_line.err | tail -1 > $OUT/${TAG}_bench_line.json

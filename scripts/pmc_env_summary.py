@@ -18,16 +18,20 @@ import sys
 out, tag = sys.argv[1], sys.argv[2]
 per_env = len(sys.argv) > 3 and sys.argv[3] == "per-env"
 J, R = 3, 4
-B_ALG = 85 + ((8 * (6 * R + 3 * J + J * R) + J * R) if per_env else 0)   # bench.py: algorithmic bytes per env-step
+B_ALG = 89 + ((8 * (6 * R + 3 * J + J * R) + J * R) if per_env else 0)   # bench.py: algorithmic bytes per env-step
 runs = {}
+# dispatches are told apart by kernel name AND grid size (threads): a per-env pass runs bench.py once at its default
+# E = 4096 and picks up the 2^22-env launches of the same kernel from bench.py's large_batch section
 for E, kern in ((4096, "env_step_kernel" if per_env else "env_step_slots_kernel"), (4194304, "env_step_kernel")):
     rec = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-        files = glob.glob(os.path.join(out, f"E{E}_{ctr}", "**", "*counter_collection.csv"), recursive=True)
+        files = glob.glob(os.path.join(out, f"E{E}_{ctr}", "**", "*counter_collection.csv"), recursive=True) or \
+            glob.glob(os.path.join(out, f"ALL_{ctr}", "**", "*counter_collection.csv"), recursive=True)
         vals = []
         for f in files:
             for r in csv.DictReader(open(f)):
-                if kern + "<" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                big = int(r["Grid_Size"]) >= (1 << 22)
+                if kern + "<" in r["Kernel_Name"] and r["Counter_Name"] == ctr and big == (E > (1 << 20)):
                     vals.append(float(r["Counter_Value"]))
         if not vals:
             continue
