@@ -109,6 +109,23 @@ def pmc_traffic(J, R, E, per_env=False):
     return None, None
 
 
+def profiled_kernel_time(kernel_substr, per_env=False):
+    """(average us, min us, calls, file) of a kernel in the latest committed rocprofv3 --kernel-trace --stats summary of
+    the env-roofline replay (scripts/collect_profiles.sh: `bench.py --mode env --steps 1 --warmup 0`, i.e. the 200-launch
+    graph of macjd_env_step_timed, warm + timed); None when no such file."""
+    import csv
+    import glob
+    pat = "r*_bench_env_per_env_kernel_stats.csv" if per_env else "r*_bench_env_roofline_kernel_stats.csv"
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", pat)), reverse=True):
+        try:
+            for r in csv.DictReader(open(f)):
+                if kernel_substr in r["Name"]:
+                    return float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, int(r["Calls"]), os.path.basename(f)
+        except Exception:
+            continue
+    return None
+
+
 def time_graph_replay(fn, dev, calls=20, replays=10):
     """Average microseconds per call of ``fn`` (a launch sequence on the current stream), replayed from a HIP graph and
     bracketed by events on the replay stream."""
@@ -268,6 +285,13 @@ def main():
                           "the rocprofv3 kernel-trace average of the same replay is committed under profiles/ (r02_bench_env_roofline_*)",
                 "traffic_measured_in_run": False,
                 "bytes_per_env_step": B_step, "envs_per_launch": E}
+    prof = profiled_kernel_time("env_step_kernel<" if (args.per_env or E >= (1 << 16)) else "env_step_slots_kernel<", args.per_env)
+    if prof is not None and E == 4096:
+        # the committed rocprofv3 summary of the same replay: its per-dispatch duration (start -> end timestamps of ONE
+        # dispatch, taken with the dispatches serialised by the profiler) is ~0.7 us above the back-to-back figure the
+        # HIP events give for a launch this short; both are stated, `frac` uses the live HIP-event time
+        roofline["profile"] = {"file": prof[3], "avg_us": round(prof[0], 3), "min_us": round(prof[1], 3), "calls": prof[2],
+                               "frac_from_avg": round(E * B_step / (prof[0] * 1e-6) / 1e9 / HBM_PEAK_GBS, 6)}
     # large-batch point of the same kernel family (2^22 envs): the HBM-bound asymptote, measured every run so the
     # launch-bound fraction at the benchmark's E is not mistaken for the kernel's streaming rate
     if rank == 0:

@@ -23,6 +23,10 @@ stats() {  # name, bench args...
   rm -rf $OUT/prof_$name
   echo "[collect] $name done"
 }
+# (0) the default bench line (train mode, other modes, CPU baseline) — un-profiled, and it leaves TunableOp's result file
+# behind, so the profiled runs below replay the chosen GEMM solutions instead of tracing the tuner's candidates
+( cd $ROOT && timeout -k 10 500 python3 bench.py 2> $OUT/${TAG}_bench_line.err | tail -1 > $OUT/${TAG}_bench_line.json )
+echo "[collect] bench line done"
 # (1) the env roofline replay alone: 1 eager step + the 200-launch graph of macjd_env_step_timed (warm + timed replay)
 stats env_roofline --mode env --steps 1 --warmup 0 --no-cpu-baseline --no-other-modes
 stats rollout --mode rollout --steps 300 --warmup 100 --no-cpu-baseline --no-other-modes
@@ -49,7 +53,3 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 python3 $ROOT/scripts/pmc_env_summary.py $D $TAG per-env > $OUT/${TAG}_env_step_per_env_pmc.json
 rm -rf $D
-# (3) the default bench line (train mode, other modes, CPU baseline)
-cd $ROOT
-timeout -k 10 500 python3 bench.py 2> $OUT/${TAG}_bench_line.err | tail -1 > $OUT/${TAG}_bench_line.json
-echo "[collect] bench line done"
