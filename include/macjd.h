@@ -181,6 +181,18 @@ int macjd_env_reset(const macjd_scenario* s, int64_t n_envs, uint8_t* track, int
 /* replaces ElectromagneticEnvironment.step (environment.py:221-477) */
 int macjd_env_step(const macjd_scenario* s, const macjd_step_io* io, void* hip_stream);
 
+/* T consecutive steps of all E environments in ONE launch, given the actions of all T steps (time-major: step t of
+   env e at offset t * t_stride + e * se + k * sx of T / P32; outputs reward / terminated / r_dpj likewise at
+   t * n_envs + e, pd / snr_with are not written).  Legal because a step's outcome depends on the environment's past
+   only through the step counter: the FSM's next state equals `detected` whatever the previous state (core/radar.py:
+   102-117), nothing else is carried over (environment.py:221-477).  So when the actions do not depend on the env's
+   outputs — the observation is static, environment.py:479-522 — the T x E env-steps of an episode batch are
+   independent work items: virtual env v = t * E + e runs (env e, step step[e] + t) in the streaming lane kernel.
+   `track` and `step` end as after the last step; io->r_dpj_sum gets the sums over the T steps.  Production
+   configuration only (Philox uniforms, float32 actions); io->u, P64 and the float64 diagnostics must be NULL. */
+int macjd_env_step_many(const macjd_scenario* s, const macjd_step_io* io, int32_t n_steps, int64_t t_stride,
+                        void* hip_stream);
+
 /* timing helper for bench.py: `iters` back-to-back env_step launches, replayed from one HIP graph on a private
    stream after the work queued on `hip_stream` has finished (as the benchmark's rollout replays them, so the
    host's enqueue rate does not enter; issued directly on `hip_stream` if the capture is refused), bracketed by

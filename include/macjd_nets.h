@@ -399,6 +399,49 @@ int macjd_mixer_fused_supported(int32_t J, int32_t S, int32_t Hh, int32_t Em);  
 int macjd_mixer_fused_forward(const macjd_mixerf_io* io, void* hip_stream);
 int macjd_mixer_fused_backward(const macjd_mixerf_io* io, void* hip_stream);
 
+/*
+ * The agent side of a WHOLE episode batch in one launch: for t = 0 .. T-1 and every (env, agent) row
+ *   h_t = GRUCell(x, h_{t-1})  with the input transform gi = W_ih ReLU(fc1 obs) + b_ih given (it does not change
+ *         within an episode: the observation is static, reference simulation/environment.py:479-522),
+ *   Q(h_t, a, P_a) for all a (MP-DQN multi-pass Q-head, core/networks.py:131-180), availability mask, epsilon-greedy
+ *   choice and gather of the chosen power (core/mac.py:59-166, utils/action_selectors.py:15-62)
+ * i.e. T x (macjd_gru_gates + two GEMMs + macjd_qhead_select) of the step-by-step rollout.  Nothing the agent
+ * computes depends on the environment's outputs when the observation is static, so the T steps of the agent need no
+ * env step in between (the env steps of the whole episode then run as ONE launch too: macjd_env_step_many).
+ *
+ * A workgroup owns 16 environments (16 J rows = J MFMA row tiles, tile j = agent j) for the whole episode: W_hh and
+ * the Q-head's h-columns live in registers as MFMA operand fragments (wave w owns hidden units [16w, 16w+16) of all
+ * three gates), h_t ping-pongs between two LDS tiles, two barriers per step, no global synchronisation at all —
+ * environments are independent.  Exact float32 (v_mfma_f32_16x16x4_f32); gate and Q-head expressions and the Philox
+ * exploration draws are those of macjd_gru_gates / macjd_qhead_select (same (row, counter) keying), so the episode equals
+ * the step-by-step rollout up to the summation order of the two matrix products.
+ * Supported: H = 64, J in {2, 3, 6}, A in {5, 9, 17} (MACJD_EUNSUPPORTED otherwise).
+ */
+typedef struct macjd_agent_episode_io {
+    int64_t n_envs;            /* E */
+    int32_t T, J, H, A;        /* steps, agents, rnn_hidden_dim, n_actions */
+    int32_t greedy_only, reserved;
+    const float* gi;    int64_t gi_ld;   /* [E*J, 3H] input transform incl. b_ih; gi_ld = 0: one row for all */
+    const float* P_all; int64_t p_ld;    /* [E*J, A] actor output; p_ld = 0: one row for all */
+    const float* h0;                     /* [E*J, H] initial hidden state or NULL = zeros (mac.init_hidden) */
+    const float* w_hh;  const float* b_hh;           /* rnn.weight_hh [3H,H], rnn.bias_hh [3H] */
+    const float* W1;    int64_t w1_ld;               /* fc2_q_head.0.weight [H, H+A+1] */
+    const float* b1;    const float* w2; const float* b2;   /* fc2_q_head.0.bias [H], .2.weight [H], .2.bias [1] */
+    const void* avail;  int32_t avail_elem_size, reserved2;  /* optional mask (static), int32 / int64 elements */
+    int64_t av_se, av_sj, av_sa;
+    const float* eps;          /* [T] exploration probability of every step (device memory) */
+    uint64_t seed;
+    const uint64_t* counter_base;   /* device scalar: step t draws with counter = *counter_base + t + 1 */
+    /* outputs, time-major staging rows of the batched runner */
+    float*   hidden;    /* [T(+1), E, J, H] contiguous: row t = post-update h_t */
+    int32_t* T_out;     /* [T, E, J] chosen discrete action */
+    float*   P_out;     /* [T, E, J] chosen power */
+    float*   h_final;   /* [E*J, H] optional: h_{T-1} (mac.hidden_states) */
+} macjd_agent_episode_io;
+
+int macjd_agent_episode_supported(int32_t J, int32_t H, int32_t A);
+int macjd_agent_episode(const macjd_agent_episode_io* io, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,7 @@ EXPORTS = [
     "macjd_mlp_forward", "macjd_mlp_forward_pair", "macjd_td_loss", "macjd_clip_adam_step", "macjd_gather_rows",
     "macjd_linear_wgrad", "macjd_linear_wgrad_workspace_floats", "macjd_linear_wgrad_many", "macjd_qhead_input", "macjd_layernorm_forward", "macjd_layernorm_param_grad", "macjd_gru_gates", "macjd_rowdot", "macjd_splitrelu_backward",
     "macjd_mixer_fused_supported", "macjd_mixer_fused_forward", "macjd_mixer_fused_backward",
+    "macjd_agent_episode_supported", "macjd_agent_episode", "macjd_env_step_many",
 ]
 
 
@@ -112,6 +113,21 @@ class MixerFusedIO(ctypes.Structure):
         ("y", ctypes.c_void_p), ("sn", ctypes.c_void_p), ("xhat", ctypes.c_void_p), ("act", ctypes.c_void_p),
         ("gy", ctypes.c_void_p), ("gq", ctypes.c_void_p), ("gout1", ctypes.c_void_p), ("g_w1raw", ctypes.c_void_p),
         ("g_wfraw", ctypes.c_void_p), ("g_v", ctypes.c_void_p),
+    ]
+
+
+class AgentEpisodeIO(ctypes.Structure):
+    """ctypes mirror of ``macjd_agent_episode_io`` (include/macjd_nets.h)."""
+    _fields_ = [
+        ("n_envs", ctypes.c_int64), ("T", ctypes.c_int32), ("J", ctypes.c_int32), ("H", ctypes.c_int32), ("A", ctypes.c_int32),
+        ("greedy_only", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("gi", ctypes.c_void_p), ("gi_ld", ctypes.c_int64), ("P_all", ctypes.c_void_p), ("p_ld", ctypes.c_int64),
+        ("h0", ctypes.c_void_p), ("w_hh", ctypes.c_void_p), ("b_hh", ctypes.c_void_p),
+        ("W1", ctypes.c_void_p), ("w1_ld", ctypes.c_int64), ("b1", ctypes.c_void_p), ("w2", ctypes.c_void_p), ("b2", ctypes.c_void_p),
+        ("avail", ctypes.c_void_p), ("avail_elem_size", ctypes.c_int32), ("reserved2", ctypes.c_int32),
+        ("av_se", ctypes.c_int64), ("av_sj", ctypes.c_int64), ("av_sa", ctypes.c_int64),
+        ("eps", ctypes.c_void_p), ("seed", ctypes.c_uint64), ("counter_base", ctypes.c_void_p),
+        ("hidden", ctypes.c_void_p), ("T_out", ctypes.c_void_p), ("P_out", ctypes.c_void_p), ("h_final", ctypes.c_void_p),
     ]
 
 
@@ -267,6 +283,12 @@ def load() -> ctypes.CDLL:
     for name in ("macjd_mixer_tail_forward", "macjd_mixer_tail_backward"):
         getattr(lib, name).restype = ctypes.c_int
         getattr(lib, name).argtypes = [ctypes.POINTER(MixerIO), ctypes.c_void_p]
+    lib.macjd_agent_episode_supported.restype = ctypes.c_int
+    lib.macjd_agent_episode_supported.argtypes = [ctypes.c_int32] * 3
+    lib.macjd_agent_episode.restype = ctypes.c_int
+    lib.macjd_agent_episode.argtypes = [ctypes.POINTER(AgentEpisodeIO), ctypes.c_void_p]
+    lib.macjd_env_step_many.restype = ctypes.c_int
+    lib.macjd_env_step_many.argtypes = [ctypes.c_void_p, ctypes.POINTER(StepIO), ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p]
     lib.macjd_mixer_fused_supported.restype = ctypes.c_int
     lib.macjd_mixer_fused_supported.argtypes = [ctypes.c_int32] * 4
     for name in ("macjd_mixer_fused_forward", "macjd_mixer_fused_backward"):

@@ -34,6 +34,7 @@ def make_args(sc, hidden, device, batch_size=32, buffer_size=None, batch_envs=40
 def _make_step_fn(cli, runner, learner, buf, args, T, mode, use_graphs, tails):
     """The per-step schedule of the benchmark (no device code here: tests drive it with a fake runner)."""
     state = {"graphed_episode": False}
+    fused = use_graphs and getattr(runner, "fused_rollout_available", lambda: False)()
 
     def step_fn(i):
         # Episodes are aligned to the regions the caller times: the warm-up steps are their own run of episodes and
@@ -48,11 +49,15 @@ def _make_step_fn(cli, runner, learner, buf, args, T, mode, use_graphs, tails):
         t = j % T
         if t == 0:
             left = region - j
-            state["graphed_episode"] = use_graphs and (left >= T or left in tails)
-            if state["graphed_episode"]:
-                runner.rollout_graphed(None if left >= T else left)
+            if fused:   # the whole (or the region's partial) episode batch: agent-episode launch + many-step env launch
+                state["graphed_episode"] = True
+                runner.rollout_fused(n_steps=None if left >= T else left)
             else:
-                runner.begin_episodes()
+                state["graphed_episode"] = use_graphs and (left >= T or left in tails)
+                if state["graphed_episode"]:
+                    runner.rollout_graphed(None if left >= T else left)
+                else:
+                    runner.begin_episodes()
         if not state["graphed_episode"]:
             runner.step(t)
         if t == T - 1:
@@ -99,7 +104,8 @@ def make_step(cli, sc, env, dev, rank, world, mode):
         if use_graphs:
             learner.enable_graphs(buf, args.batch_size)
     tails = set()
-    if use_graphs:
+    fused_rollout = use_graphs and runner.fused_rollout_available()
+    if use_graphs and not fused_rollout:
         runner.enable_graph()
         # the partial episode at the end of the warm-up / timed region gets its own (shorter) graph, so every step of
         # the run is replayed from a graph whatever --steps / --warmup are
@@ -110,7 +116,9 @@ def make_step(cli, sc, env, dev, rank, world, mode):
 
     extra = {"hidden": cli.hidden, "train_batch_episodes": args.batch_size if mode == "train" else 0,
              "train_calls_per_step": 1 if mode == "train" else 0, "hip_graphs": bool(use_graphs), "gemm_tuning": bool(gemm_tuning),
-             "replay_capacity_episodes": args.buffer_size}
+             "replay_capacity_episodes": args.buffer_size,
+             "rollout": "fused: agent-episode launch + many-step env launch per episode batch" if fused_rollout else
+                        ("HIP graph of the step-by-step rollout" if use_graphs else "eager step-by-step")}
     return step_fn, extra
 
 

@@ -154,6 +154,9 @@ struct FastStepIO {
     const uint8_t* pe_flags;
     int64_t pe_stride;
     int32_t T_se, T_sx, P_se, P_sx, k_se, k_sx, pd_se, pd_sx, sw_se, sw_sx, pe_tile;
+    // macjd_env_step_many: many_T > 0 runs many_T steps of each of n_envs envs as many_T * n_envs work items (time-major:
+    // item v = t * n_envs + e), actions of step t at + t * t_stride elements
+    int32_t many_T, t_stride;
     // members of macjd_step_io this configuration never has (compile-time constants: the code paths fold away)
     static constexpr const double* u = nullptr;
     static constexpr int64_t u_se = 0, u_sx = 0;
@@ -202,24 +205,39 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
     const int32_t episode_limit = tb->episode_limit;
     const bool arith32 = FAST ? true : ((io.P32 != nullptr) && !(io.flags & MACJD_STEP_ARITH_F64));
 
-    auto env_step_one = [&](const int64_t e) {
+    auto env_step_one = [&](const int64_t e_item) {
+        // many-step launches (production variant only, macjd_env_step_many): work item -> (step t, env e);
+        // single-step launches: item = env, t = 0
+        int64_t e = e_item;
+        int32_t tt = 0;
+        bool many = false, last_t = true;
+        if constexpr (FAST) {
+            if (io.many_T > 0) {
+                many = true;
+                tt = (int32_t)(e_item / io.n_envs);
+                e = e_item - (int64_t)tt * io.n_envs;
+                last_t = (tt == io.many_T - 1);
+            }
+        }
+        int64_t act_extra = 0;   // element offset of step t's actions
+        if constexpr (FAST) act_extra = (int64_t)tt * io.t_stride;
         // Element (env e, item k) of a caller-strided array.  Production variant: the BYTE offset is formed in 32 bits
         // (the host checks that every offset of the launch fits) and added to the wave-uniform base pointer, which is
         // the SGPR-base + 32-bit-VGPR-offset addressing form of global_load / global_store — no 64-bit VALU address
         // arithmetic per access (~50 instructions per env-step at 3j/4r).
-        auto at = [&](auto* base, auto se, int k, auto sx) -> decltype(*base)& {
+        auto at = [&](auto* base, int64_t env, auto se, int k, auto sx, int64_t extra = 0) -> decltype(*base)& {
             using T_ = std::remove_reference_t<decltype(*base)>;
             if constexpr (FAST) {
-                const uint32_t off = ((uint32_t)e * (uint32_t)se + (uint32_t)k * (uint32_t)sx) * (uint32_t)sizeof(T_);
+                const uint32_t off = ((uint32_t)env * (uint32_t)se + (uint32_t)k * (uint32_t)sx + (uint32_t)extra) * (uint32_t)sizeof(T_);
                 using C_ = std::conditional_t<std::is_const_v<T_>, const char, char>;
                 return *reinterpret_cast<T_*>(reinterpret_cast<C_*>(base) + off);
             } else {
-                return base[e * (int64_t)se + (int64_t)k * (int64_t)sx];
+                return base[env * (int64_t)se + (int64_t)k * (int64_t)sx + extra];
             }
         };
-        const int32_t step_before = at(io.step, 1, 0, 0);
+        const int32_t step_before = at(io.step, e, 1, 0, 0) + tt;
         const int32_t step_count = step_before + 1;  // environment.py:235
-        const uint32_t episode = io.episode ? (uint32_t)at(io.episode, 1, 0, 0) : 0u;
+        const uint32_t episode = io.episode ? (uint32_t)at(io.episode, e, 1, 0, 0) : 0u;
         // Monte-Carlo uniforms of this env-step (R radar slots, then one per valid deception action): every Philox
         // block is generated once (ceil((R + J) / 4) blocks: 2 at 3j/4r); the radar pass reads its words at
         // compile-time indices, a deception action selects word R + n_dec.
@@ -264,7 +282,7 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
                 for (int j = 0; j < NJ; ++j) pv_j[k * NJ + j] = pe[(int64_t)(6 * R + k * J + j) * ps];   // pmin, pmax, gj
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int32_t Tj = at(io.T, io.T_se, j, io.T_sx);
+                const int32_t Tj = at(io.T, e, io.T_se, j, io.T_sx, act_extra);
                 const int tj = ((Tj >= 1) && (Tj <= 2 * R)) ? ((Tj + 1) / 2 - 1) : 0;
                 gv_denom[j] = pe[(int64_t)(6 * R + 3 * J + j * R + tj) * ps];
                 gv_gr[j] = pe[(int64_t)(5 * R + tj) * ps];
@@ -313,7 +331,7 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
         for (int j = 0; j < NJ; ++j) {
             if (!JT && j >= J) break;
             // ---- action decode, environment.py:249-268 ----
-            const int32_t T = at(io.T, io.T_se, j, io.T_sx);
+            const int32_t T = at(io.T, e, io.T_se, j, io.T_sx, act_extra);
             const bool is_jamming = (T >= 1) && (T <= 2 * R);
             const int target = is_jamming ? ((T + 1) / 2 - 1) : 0;
             const int jtype = T % 2;  // 1 = suppression, 0 = deception (only read when is_jamming)
@@ -324,14 +342,14 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
             double actual_d, norm;
             float actual_f = 0.0f;
             if (arith32) {
-                float Pc = at(io.P32, io.P_se, j, io.P_sx);
+                float Pc = at(io.P32, e, io.P_se, j, io.P_sx, act_extra);
                 Pc = Pc < 0.0f ? 0.0f : (Pc > 1.0f ? 1.0f : Pc);  // np.clip, NaN propagates
                 actual_f = (float)pmin + Pc * (float)power_range;
                 actual_d = (double)actual_f;
                 norm = (power_range > 1e-6) ? (double)((actual_f - (float)pmin) / (float)power_range) : 0.0;
             } else {
                 double Pc = io.P64 ? io.P64[e * io.P_se + (int64_t)j * io.P_sx]
-                                   : (double)at(io.P32, io.P_se, j, io.P_sx);
+                                   : (double)at(io.P32, e, io.P_se, j, io.P_sx, act_extra);
                 Pc = Pc < 0.0 ? 0.0 : (Pc > 1.0 ? 1.0 : Pc);
                 actual_d = pmin + Pc * power_range;
                 norm = (power_range > 1e-6) ? (actual_d - pmin) / power_range : 0.0;
@@ -468,27 +486,27 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
         for (int r = 0; r < NR; ++r) {
             if (!RT && r >= R) break;
             const double snr_rep = (snr_w[r] > 0.0) ? snr_w[r] : 0.0;         // :333
-            at(io.track, io.k_se, r, io.k_sx) = (track_bits >> r) & 1u;
-            if (io.pd) at(io.pd, io.pd_se, r, io.pd_sx) = (float)pd_r[r];
-            if (io.snr_with) at(io.snr_with, io.sw_se, r, io.sw_sx) = (float)snr_rep;
+            if (last_t) at(io.track, e, io.k_se, r, io.k_sx) = (track_bits >> r) & 1u;
+            if (io.pd) at(io.pd, e, io.pd_se, r, io.pd_sx) = (float)pd_r[r];
+            if (io.snr_with) at(io.snr_with, e, io.sw_se, r, io.sw_sx) = (float)snr_rep;
             if (!FAST && io.pd64) io.pd64[e * R + r] = pd_r[r];
             if (!FAST && io.snr64) io.snr64[e * R + r] = snr_rep;
         }
         r_j += r_j_dec;                          // :454
         const double reward = r_d + r_p + r_j;  // :457
 
-        at(io.step, 1, 0, 0) = step_count;
-        if (io.terminated) at(io.terminated, 1, 0, 0) = (step_count >= episode_limit) ? 1 : 0;  // :460
-        if (io.reward) at(io.reward, 1, 0, 0) = (float)reward;
+        if (!many) at(io.step, e, 1, 0, 0) = step_count;   // many-step: advanced by env_advance_kernel afterwards
+        if (io.terminated) at(io.terminated, e_item, 1, 0, 0) = (step_count >= episode_limit) ? 1 : 0;  // :460
+        if (io.reward) at(io.reward, e_item, 1, 0, 0) = (float)reward;
         if (io.r_dpj) {
-            at(io.r_dpj, 3, 0, 1) = (float)r_d;
-            at(io.r_dpj, 3, 1, 1) = (float)r_p;
-            at(io.r_dpj, 3, 2, 1) = (float)r_j;
+            at(io.r_dpj, e_item, 3, 0, 1) = (float)r_d;
+            at(io.r_dpj, e_item, 3, 1, 1) = (float)r_p;
+            at(io.r_dpj, e_item, 3, 2, 1) = (float)r_j;
         }
-        if (io.r_dpj_sum) {
-            at(io.r_dpj_sum, 3, 0, 1) += (float)r_d;
-            at(io.r_dpj_sum, 3, 1, 1) += (float)r_p;
-            at(io.r_dpj_sum, 3, 2, 1) += (float)r_j;
+        if (io.r_dpj_sum && !many) {   // many-step: summed over the steps by env_advance_kernel
+            at(io.r_dpj_sum, e, 3, 0, 1) += (float)r_d;
+            at(io.r_dpj_sum, e, 3, 1, 1) += (float)r_p;
+            at(io.r_dpj_sum, e, 3, 2, 1) += (float)r_j;
         }
         if (!FAST && io.out64) {
             io.out64[e * 4 + 0] = reward;
@@ -500,8 +518,8 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
     if constexpr (FAST) {
         // one env per lane, no grid-stride loop: inside a loop every argument and table constant is loop-invariant,
         // gets hoisted and stays live for the whole body (SGPR spills); straight-line code loads them where used
-        const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        if (e < io.n_envs) env_step_one(e);
+        const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (item < io.n_envs * (io.many_T > 0 ? io.many_T : 1)) env_step_one(item);
     } else {
         for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < io.n_envs;
              e += (int64_t)gridDim.x * blockDim.x)
@@ -744,6 +762,22 @@ __global__ void env_reset_kernel(int64_t n_envs, int R, uint8_t* track, int64_t 
     }
 }
 
+// second half of macjd_env_step_many: the step counters advance by T, the per-episode reward-component sums get the T
+// steps' (r_d, r_p, r_j) added in step order (deterministic)
+__global__ void env_advance_kernel(int64_t n_envs, int32_t T, int32_t* step, const float* r_dpj, float* r_dpj_sum) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_envs; e += (int64_t)gridDim.x * blockDim.x) {
+        step[e] += T;
+        if (r_dpj && r_dpj_sum) {
+            float a = r_dpj_sum[e * 3 + 0], b = r_dpj_sum[e * 3 + 1], c = r_dpj_sum[e * 3 + 2];
+            for (int t = 0; t < T; ++t) {
+                const float* p = r_dpj + ((int64_t)t * n_envs + e) * 3;
+                a += p[0]; b += p[1]; c += p[2];
+            }
+            r_dpj_sum[e * 3 + 0] = a; r_dpj_sum[e * 3 + 1] = b; r_dpj_sum[e * 3 + 2] = c;
+        }
+    }
+}
+
 }  // namespace macjd
 
 using macjd::DevTables;
@@ -844,8 +878,9 @@ static int validate_io(const macjd_scenario* s, const macjd_step_io* io) {
     return MACJD_OK;
 }
 
-static int launch_step(const macjd_scenario* s, const macjd_step_io* io, hipStream_t stream) {
-    const int64_t E = io->n_envs;
+static int launch_step(const macjd_scenario* s, const macjd_step_io* io, hipStream_t stream, int32_t many_T = 0,
+                       int64_t t_stride = 0) {
+    const int64_t E = io->n_envs * (many_T > 0 ? many_T : 1);   // work items of the launch
     const int J = s->host.J, R = s->host.R;
     const bool has_slot_kernel = (J == 3 && R == 4) || (J == 6 && R == 8) || (J == 12 && R == 16) || (J == 2 && R == 2);
     // measured crossover on MI355X (3j/4r, round 2): slot kernel 3.9 / 4.2 / 7.3 / 21.8 us vs lane kernel 5.6 / 5.7 /
@@ -855,6 +890,7 @@ static int launch_step(const macjd_scenario* s, const macjd_step_io* io, hipStre
     if ((io->flags & MACJD_STEP_SLOT_KERNEL) && has_slot_kernel) slot_kernel = true;
     const bool per_env = io->pe_tables != nullptr;
     if (per_env) slot_kernel = false;   // per-env tables: lane-per-env kernel (each lane streams its own SoA column)
+    if (many_T > 0) slot_kernel = false;
     if (slot_kernel) {  // one workgroup per 64 envs
         const dim3 g((unsigned)((E + 63) / 64));
 #define MACJD_SLOTS(JT, RT, NJW, NRW) \
@@ -877,18 +913,21 @@ static int launch_step(const macjd_scenario* s, const macjd_step_io* io, hipStre
         // production configuration (Philox uniforms, float32 actions / power arithmetic, no float64 diagnostics,
         // strides that fit int32)
         // ... and every byte offset of the launch below 2^32 (the production variant forms them in 32 bits)
-        auto span_ok = [&](int64_t se, int64_t sx, int items, int64_t elem) {
-            return se >= 0 && sx >= 0 && ((E - 1) * se + (int64_t)(items - 1) * sx + 1) * elem < (int64_t)1 << 32;
+        const int64_t En = io->n_envs;
+        auto span_ok = [&](int64_t se, int64_t sx, int items, int64_t elem, int64_t extra = 0) {
+            return se >= 0 && sx >= 0 && extra >= 0 &&
+                   ((En - 1) * se + (int64_t)(items - 1) * sx + extra + 1) * elem < (int64_t)1 << 32;
         };
+        const int64_t act_extra = many_T > 0 ? (int64_t)(many_T - 1) * t_stride : 0;
         const bool fast = !io->u && io->P32 && !(io->flags & MACJD_STEP_ARITH_F64) && !io->out64 && !io->pd64 &&
                           !io->snr64 && !io->prj64 && (E + block - 1) / block <= 0x7fffffff &&
-                          span_ok(io->T_se, io->T_sx, J, 4) && span_ok(io->P_se, io->P_sx, J, 4) &&
-                          span_ok(io->k_se, io->k_sx, R, 1) && span_ok(3, 1, 3, 4) &&
+                          span_ok(io->T_se, io->T_sx, J, 4, act_extra) && span_ok(io->P_se, io->P_sx, J, 4, act_extra) &&
+                          span_ok(io->k_se, io->k_sx, R, 1) && (E * 3 + 3) * 4 < ((int64_t)1 << 32) && t_stride <= INT32_MAX &&
                           (!io->pd || span_ok(io->pd_se, io->pd_sx, R, 4)) &&
                           (!io->snr_with || span_ok(io->sw_se, io->sw_sx, R, 4));
         macjd::FastStepIO f{};
         if (fast) {
-            f.n_envs = io->n_envs; f.env_offset = io->env_offset; f.seed = io->seed;
+            f.n_envs = io->n_envs; f.env_offset = io->env_offset; f.seed = io->seed;   // (n_envs: real envs, not work items)
             f.T = io->T; f.P32 = io->P32; f.episode = io->episode; f.track = io->track; f.step = io->step;
             f.reward = io->reward; f.r_dpj = io->r_dpj; f.terminated = io->terminated; f.pd = io->pd;
             f.snr_with = io->snr_with; f.r_dpj_sum = io->r_dpj_sum; f.pe_tables = io->pe_tables;
@@ -896,6 +935,10 @@ static int launch_step(const macjd_scenario* s, const macjd_step_io* io, hipStre
             f.T_se = (int32_t)io->T_se; f.T_sx = (int32_t)io->T_sx; f.P_se = (int32_t)io->P_se; f.P_sx = (int32_t)io->P_sx;
             f.k_se = (int32_t)io->k_se; f.k_sx = (int32_t)io->k_sx; f.pd_se = (int32_t)io->pd_se; f.pd_sx = (int32_t)io->pd_sx;
             f.sw_se = (int32_t)io->sw_se; f.sw_sx = (int32_t)io->sw_sx;
+            f.many_T = many_T; f.t_stride = (int32_t)t_stride;
+        } else if (many_T > 0) {
+            return set_err(MACJD_EUNSUPPORTED, "%s", "macjd_env_step_many: production configuration only (Philox uniforms, "
+                           "float32 actions, no float64 diagnostics, offsets below 2^32 bytes)");
         }
 #define MACJD_LAUNCH(JT, RT)                                                                                          \
     do {                                                                                                              \
@@ -912,7 +955,9 @@ static int launch_step(const macjd_scenario* s, const macjd_step_io* io, hipStre
         else if (J == 6 && R == 8) MACJD_LAUNCH(6, 8);
         else if (J == 12 && R == 16) MACJD_LAUNCH(12, 16);
         else if (J == 2 && R == 2) MACJD_LAUNCH(2, 2);
-        else {   // generic sizes: one (non-FAST) variant per table mode
+        else if (many_T > 0) {
+            return set_err(MACJD_EUNSUPPORTED, "%s", "macjd_env_step_many: scenario size without a compiled production variant");
+        } else {   // generic sizes: one (non-FAST) variant per table mode
             if (per_env) hipLaunchKernelGGL((macjd::env_step_kernel<0, 0, true, false, macjd_step_io>), g, b, 0, stream, s->dev, *io);
             else hipLaunchKernelGGL((macjd::env_step_kernel<0, 0, false, false, macjd_step_io>), g, b, 0, stream, s->dev, *io);
         }
@@ -928,6 +973,24 @@ int macjd_env_step(const macjd_scenario* s, const macjd_step_io* io, void* hip_s
     if (rc != MACJD_OK) return rc;
     if (io->n_envs == 0) return MACJD_OK;
     return launch_step(s, io, (hipStream_t)hip_stream);
+}
+
+int macjd_env_step_many(const macjd_scenario* s, const macjd_step_io* io, int32_t n_steps, int64_t t_stride, void* hip_stream) {
+    int rc = validate_io(s, io);
+    if (rc != MACJD_OK) return rc;
+    if (n_steps < 1 || t_stride < 0) return set_err(MACJD_EINVAL, "%s", "macjd_env_step_many: bad n_steps / t_stride");
+    if (io->pd || io->snr_with) return set_err(MACJD_EINVAL, "%s", "macjd_env_step_many: pd / snr_with are not written (pass NULL)");
+    if (io->r_dpj_sum && !io->r_dpj) return set_err(MACJD_EINVAL, "%s", "macjd_env_step_many: r_dpj_sum needs the per-step r_dpj buffer");
+    if (io->n_envs == 0) return MACJD_OK;
+    rc = launch_step(s, io, (hipStream_t)hip_stream, n_steps, t_stride);
+    if (rc != MACJD_OK) return rc;
+    int64_t grid = (io->n_envs + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(macjd::env_advance_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)hip_stream, io->n_envs,
+                       n_steps, io->step, io->r_dpj, io->r_dpj_sum);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_env_step_many launch: %s", hipGetErrorString(err));
+    return MACJD_OK;
 }
 
 int macjd_env_step_timed(const macjd_scenario* s, const macjd_step_io* io, int iters, void* hip_stream,

@@ -1,0 +1,302 @@
+// macjd_episode.hip — the agent side of a whole episode batch as ONE launch (C-ABI: include/macjd_nets.h,
+// macjd_agent_episode_io): for every step t, h_t = GRUCell(x, h_{t-1}); Q(h_t, a, P_a) for all actions (MP-DQN
+// multi-pass Q-head); mask; epsilon-greedy; gather of the chosen power.  Reference: core/mac.py:59-166 driven by
+// runners/episode_runner.py:27-181, one env step at a time; here T steps of E environments without returning to the
+// host or to a launch boundary.
+//
+// Why this is legal: the observation of this environment is static (simulation/environment.py:479-522), so the GRU's
+// input transform gi = W_ih ReLU(fc1 obs) + b_ih and the actor's output P are per-episode constants, and nothing the
+// agent computes at step t depends on what the environment returned at step t-1.  Environments are independent of
+// each other as well: a workgroup that owns 16 environments never needs anything from another workgroup.
+//
+// Mapping (J agents, H = 64 hidden units, A actions):
+//   * workgroup = 16 consecutive environments = J MFMA row tiles (tile j = agent j, row = env within the group);
+//     4 waves, one per SIMD; grid = E / 16 (256 workgroups at the benchmark's E = 4096: the whole chip);
+//   * wave w owns hidden units U_w = [16w, 16w+16) of all three gates: its 3 x 4 W_hh fragments (k = 64 -> 4 quads)
+//     and the 4 fragments of the Q-head's h-columns stay in VGPRs for the whole episode (64 registers);
+//   * per step: (1) gh tiles (r, z, n) x J by v_mfma_f32_16x16x4_f32, A operand = h_{t-1} from LDS (ds_read_b128,
+//     permuted-k quads as in macjd_mlp.hip); (2) gates on the accumulator tiles in registers (the wave holds r, z, n of
+//     the SAME hidden units), h_t -> its own registers, the other LDS tile (ping-pong) and the staging row in HBM;
+//     barrier; (3) base = W1[:, :H] h_t + b1 for the wave's 16 Q-head units -> LDS; barrier; (4) all-action Q-head:
+//     wave j = agent tile j, lane = (row, quarter of the 64 units): 16 units x A actions per lane with the action /
+//     power columns of W1 and w2 read from LDS (broadcast), quarter sums by two xor shuffles; (5) the lanes of
+//     quarter 0 select: availability mask, first arg-max, epsilon-greedy with the Philox draw of (row, counter_base +
+//     t + 1) — the keying of macjd_qhead_select — and write the chosen action / power of (t, env, agent).
+//   Two barriers per step; LDS: 2 x J x 16 x 72 floats of h, J x 16 x 72 of base, (A + 2) x 64 of Q-head columns.
+// Numerics: exact float32 everywhere; the gate expressions are those of gru_gates_kernel (IEEE division, expf), the
+// Q-head expressions those of qhead_select_kernel; only the summation order of the two products differs from the
+// step-by-step path (library GEMM + split over 8 waves), i.e. ~1e-7 relative on h and Q.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/macjd.h"
+#include "../../include/macjd_nets.h"
+#include "macjd_err.h"
+#include "macjd_philox.h"
+
+namespace macjd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+
+constexpr int EP_H = 64;
+constexpr int EP_LD = EP_H + 8;   // LDS pitch (= 8 mod 16 floats: conflict-free ds_read_b128 fragments)
+constexpr int EP_KQ = EP_H / 16;  // quads of a K = 64 product
+
+template <int J, int A>
+__global__ void __launch_bounds__(256) agent_episode_kernel(const macjd_agent_episode_io io) {
+    static_assert(J <= 8, "one wave per agent tile in the Q-head phase, two passes above 4");
+    __shared__ __attribute__((aligned(16))) float Hl[2][J][16 * EP_LD];   // h_{t-1} / h_t, ping-pong
+    __shared__ __attribute__((aligned(16))) float Bl[J][16 * EP_LD];      // Q-head base of the current step
+    __shared__ float Wq[(A + 2) * EP_H];   // Q-head: action columns W1[u][H + a] at [a][u], power column at [A][u], w2 at [A+1][u]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    const int64_t e0 = (int64_t)blockIdx.x * 16;
+    const int T = io.T;
+    const int64_t E = io.n_envs;
+
+    // ---- episode constants into registers / LDS -------------------------------------------------------------
+    // weight fragments (B operands): rows gate * 64 + 16 wave + li of W_hh, row 16 wave + li of W1's h-columns
+    f32x4 Bh[3][EP_KQ], Bq[EP_KQ];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int Q = 0; Q < EP_KQ; ++Q)
+            Bh[c][Q] = *reinterpret_cast<const f32x4*>(io.w_hh + (int64_t)(c * EP_H + 16 * wave + li) * EP_H + 16 * Q + 4 * g);
+#pragma unroll
+    for (int Q = 0; Q < EP_KQ; ++Q)
+        Bq[Q] = *reinterpret_cast<const f32x4_u*>(io.W1 + (int64_t)(16 * wave + li) * io.w1_ld + 16 * Q + 4 * g);
+    const int u = 16 * wave + li;          // this lane's hidden unit (gates) / Q-head unit (base) in the C layout
+    float bhh[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) bhh[c] = io.b_hh[c * EP_H + u];
+    const float b1u = io.b1[u];
+    // C layout of a 16 x 16 tile: lane holds rows 4g + r (r = 0..3) of column li.  gi of (tile j, row 4g + r), unit u:
+    float giv[J][4][3], hreg[J][4];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t e = e0 + 4 * g + r;
+            const int64_t n = (e < E ? e : E - 1) * J + j;          // clamped: rows past E are computed, never stored
+#pragma unroll
+            for (int c = 0; c < 3; ++c) giv[j][r][c] = io.gi[n * io.gi_ld + c * EP_H + u];
+            hreg[j][r] = io.h0 ? io.h0[n * EP_H + u] : 0.0f;
+            Hl[0][j][(4 * g + r) * EP_LD + u] = hreg[j][r];
+        }
+    for (int idx = threadIdx.x; idx < (A + 2) * EP_H; idx += 256) {
+        const int a = idx / EP_H, uu = idx - a * EP_H;
+        Wq[idx] = (a <= A) ? io.W1[(int64_t)uu * io.w1_ld + EP_H + a] : io.w2[uu];
+    }
+    const float b2 = io.b2[0];
+    // Q-head phase roles: wave = agent tile (waves >= J idle there; J > 4: a second pass), lane = (row qr, quarter qq)
+    const int qr = lane & 15, qq = lane >> 4;
+    float pv[(J + 3) / 4][A];         // the row's actor output P[a] (static within the episode)
+    uint64_t avail_bits[(J + 3) / 4];
+    int n_avail[(J + 3) / 4];
+#pragma unroll
+    for (int pass = 0; pass < (J + 3) / 4; ++pass) {
+        const int j = wave + 4 * pass;
+        const int64_t e = e0 + qr;
+        const int64_t ec = e < E ? e : E - 1;
+        const int64_t n = ec * J + (j < J ? j : 0);
+        avail_bits[pass] = 0;
+        n_avail[pass] = 0;
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            pv[pass][a] = io.P_all[n * io.p_ld + a];
+            bool av = true;
+            if (io.avail) {
+                const int64_t off = ec * io.av_se + (int64_t)(j < J ? j : 0) * io.av_sj + (int64_t)a * io.av_sa;
+                av = (io.avail_elem_size == 8) ? (((const int64_t*)io.avail)[off] != 0) : (((const int32_t*)io.avail)[off] != 0);
+            }
+            avail_bits[pass] |= av ? (1ull << a) : 0ull;
+            n_avail[pass] += av ? 1 : 0;
+        }
+    }
+    const uint64_t ctr_base = io.counter_base ? io.counter_base[0] : 0ull;
+    __syncthreads();
+
+    for (int t = 0; t < T; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        // ---- (1) gh = W_hh h_{t-1} for this wave's units, all gates, all agent tiles ----
+        f32x4 acc[J][3];
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int Q = 0; Q < EP_KQ; ++Q) {
+            f32x4 a[J];
+#pragma unroll
+            for (int j = 0; j < J; ++j) a[j] = *reinterpret_cast<const f32x4*>(&Hl[cur][j][li * EP_LD + 16 * Q + 4 * g]);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        acc[j][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][jj], Bh[c][Q][jj], acc[j][c], 0, 0, 0);
+        }
+        // ---- (2) gates (torch.nn.GRUCell, gate order r, z, n; expressions of gru_gates_kernel) ----
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float hr = acc[j][0][r] + bhh[0], hz = acc[j][1][r] + bhh[1], hn = acc[j][2][r] + bhh[2];
+                const float rg = 1.0f / (1.0f + expf(-(giv[j][r][0] + hr)));
+                const float zg = 1.0f / (1.0f + expf(-(giv[j][r][1] + hz)));
+                const float nn = 1.0f - 2.0f / (expf(2.0f * (giv[j][r][2] + rg * hn)) + 1.0f);
+                const float hnew = (hreg[j][r] - nn) * zg + nn;
+                hreg[j][r] = hnew;
+                const int row = 4 * g + r;
+                Hl[nxt][j][row * EP_LD + u] = hnew;
+                const int64_t e = e0 + row;
+                if (e < E) io.hidden[(((int64_t)t * E + e) * J + j) * EP_H + u] = hnew;   // staging row t: post-update h_t
+            }
+        __syncthreads();
+        // ---- (3) Q-head base = W1[:, :H] h_t + b1 for this wave's 16 units ----
+        {
+            f32x4 ab[J];
+#pragma unroll
+            for (int j = 0; j < J; ++j) ab[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int Q = 0; Q < EP_KQ; ++Q) {
+                f32x4 a[J];
+#pragma unroll
+                for (int j = 0; j < J; ++j) a[j] = *reinterpret_cast<const f32x4*>(&Hl[nxt][j][li * EP_LD + 16 * Q + 4 * g]);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int j = 0; j < J; ++j) ab[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][jj], Bq[Q][jj], ab[j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Bl[j][(4 * g + r) * EP_LD + u] = ab[j][r] + b1u;
+        }
+        __syncthreads();
+        // ---- (4) all-action Q-head + (5) selection: wave = agent tile ----
+        const float epsilon = io.greedy_only ? 0.0f : io.eps[t];
+#pragma unroll
+        for (int pass = 0; pass < (J + 3) / 4; ++pass) {
+            const int j = wave + 4 * pass;   // wave-uniform
+            if (j < J) {
+                float q[A];
+#pragma unroll
+                for (int a = 0; a < A; ++a) q[a] = 0.0f;
+                const float* brow = &Bl[j][qr * EP_LD + 16 * qq];
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + 4 * k4);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int uu = 16 * qq + 4 * k4 + kk;
+                        const float wp = Wq[A * EP_H + uu], w2u = Wq[(A + 1) * EP_H + uu];
+#pragma unroll
+                        for (int a = 0; a < A; ++a) {
+                            float v = b4[kk] + Wq[a * EP_H + uu];          // (W_h h + b1)[u] + W1[u, H + a]
+                            v = fmaf(pv[pass][a], wp, v);                  // + W1[u, H + A] * P_a
+                            v = fmaxf(v, 0.0f);                            // ReLU (networks.py:77)
+                            q[a] = fmaf(v, w2u, q[a]);                     // second layer (networks.py:78)
+                        }
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < A; ++a) {
+                    q[a] += __shfl_xor(q[a], 16, 64);
+                    q[a] += __shfl_xor(q[a], 32, 64);
+                    q[a] += b2;
+                }
+                const int64_t e = e0 + qr;
+                if (qq == 0 && e < E) {
+                    // mask, first arg-max, epsilon-greedy (mac.py:142-146, action_selectors.py:34-62): as qhead_select_kernel
+                    int best = 0;
+                    float bestq = -INFINITY;
+#pragma unroll
+                    for (int a = 0; a < A; ++a) {
+                        const float qa = ((avail_bits[pass] >> a) & 1ull) ? q[a] : -INFINITY;
+                        if (qa > bestq) { bestq = qa; best = a; }
+                    }
+                    int chosen = best;
+                    const int64_t n = e * J + j;
+                    if (epsilon > 0.0f) {
+                        const uint64_t counter = ctr_base + (uint64_t)(t + 1);
+                        const Philox4 rr = philox4x32_10((uint32_t)n, (uint32_t)((uint64_t)n >> 32), (uint32_t)counter,
+                                                         (uint32_t)(counter >> 32), (uint32_t)io.seed, (uint32_t)(io.seed >> 32));
+                        const float u_pick = (float)(rr.v[0] >> 8) * (1.0f / 16777216.0f);
+                        if (u_pick < epsilon) {
+                            const int pool = n_avail[pass] > 0 ? n_avail[pass] : A;
+                            int k = (int)(((uint64_t)rr.v[1] * (uint64_t)pool) >> 32);
+                            chosen = 0;
+#pragma unroll
+                            for (int a = 0; a < A; ++a) {
+                                const bool av = (n_avail[pass] > 0) ? ((avail_bits[pass] >> a) & 1ull) : true;
+                                if (av) { if (k == 0) chosen = a; --k; }
+                            }
+                        }
+                    }
+                    float pc = 0.0f;
+#pragma unroll
+                    for (int a = 0; a < A; ++a) pc = (a == chosen) ? pv[pass][a] : pc;
+                    const int64_t o = ((int64_t)t * E + e) * J + j;
+                    io.T_out[o] = chosen;
+                    io.P_out[o] = pc;
+                }
+            }
+        }
+        // no barrier here: the next step's (1) reads Hl[nxt] (complete since the barrier after (2)) and its (2) writes
+        // Hl[cur], which nobody reads any more; its (3) overwrites Bl only after the barrier that follows its (2), which
+        // every wave passes after finishing this step's (4)
+    }
+    if (io.h_final) {
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t e = e0 + 4 * g + r;
+                if (e < E) io.h_final[(e * J + j) * EP_H + u] = hreg[j][r];
+            }
+    }
+}
+
+}  // namespace macjd
+
+extern "C" int macjd_agent_episode_supported(int32_t J, int32_t H, int32_t A) {
+    return (H == macjd::EP_H) && (J == 2 || J == 3 || J == 6) && (A == 5 || A == 9 || A == 17);
+}
+
+extern "C" int macjd_agent_episode(const macjd_agent_episode_io* io, void* hip_stream) {
+    using namespace macjd;
+    if (!io) return set_err(MACJD_EINVAL, "%s", "macjd_agent_episode: NULL io");
+    if (!macjd_agent_episode_supported(io->J, io->H, io->A))
+        return set_err(MACJD_EUNSUPPORTED, "%s", "macjd_agent_episode: unsupported J / H / A (see include/macjd_nets.h)");
+    if (io->n_envs < 0 || io->T < 1 || !io->gi || !io->P_all || !io->w_hh || !io->b_hh || !io->W1 || !io->b1 || !io->w2 ||
+        !io->b2 || !io->hidden || !io->T_out || !io->P_out || (!io->greedy_only && !io->eps))
+        return set_err(MACJD_EINVAL, "%s", "macjd_agent_episode: bad n_envs / T or NULL pointer");
+    if ((io->gi_ld != 0 && io->gi_ld < 3 * io->H) || (io->p_ld != 0 && io->p_ld < io->A) || io->w1_ld < io->H + io->A + 1)
+        return set_err(MACJD_EINVAL, "%s", "macjd_agent_episode: row stride smaller than the row");
+    if (io->avail && io->avail_elem_size != 4 && io->avail_elem_size != 8)
+        return set_err(MACJD_EINVAL, "%s", "macjd_agent_episode: avail_elem_size must be 4 or 8");
+    if (((uintptr_t)io->w_hh) & 15) return set_err(MACJD_EINVAL, "%s", "macjd_agent_episode: w_hh must be 16-byte aligned");
+    if (io->n_envs == 0) return MACJD_OK;
+    const dim3 grid((unsigned)((io->n_envs + 15) / 16)), block(256);
+    hipStream_t s = (hipStream_t)hip_stream;
+#define MACJD_EP(J_, A_) hipLaunchKernelGGL((agent_episode_kernel<J_, A_>), grid, block, 0, s, *io)
+#define MACJD_EP_J(J_)                     \
+    do {                                   \
+        if (io->A == 5) MACJD_EP(J_, 5);   \
+        else if (io->A == 9) MACJD_EP(J_, 9); \
+        else MACJD_EP(J_, 17);             \
+    } while (0)
+    if (io->J == 2) MACJD_EP_J(2);
+    else if (io->J == 3) MACJD_EP_J(3);
+    else MACJD_EP_J(6);
+#undef MACJD_EP_J
+#undef MACJD_EP
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_agent_episode: %s", hipGetErrorString(err));
+    return MACJD_OK;
+}

@@ -151,6 +151,68 @@ def qhead_select(base, P_all, W1, w2, b2, H: int, A: int, n_agents: int, avail: 
     return T64, Pv.unsqueeze(-1), T32v, Q
 
 
+def agent_episode_supported(J: int, H: int, A: int) -> bool:
+    return bool(_native.load().macjd_agent_episode_supported(int(J), int(H), int(A)))
+
+
+def agent_episode(gi, P_all, h0, w_hh, b_hh, W1, b1, w2, b2, n_envs: int, n_agents: int, T: int, avail, eps_sched,
+                  greedy_only: bool, seed: int, counter_base, hidden_out, T_out, P_out, h_final=None):
+    """All T agent steps of an episode batch in ONE launch (csrc/macjd_episode.hip; include/macjd_nets.h,
+    macjd_agent_episode_io): GRU cell from the static input transform ``gi`` [E*J or 1, 3H], all-action MP-DQN Q-head on
+    the static actor output ``P_all`` [E*J or 1, A], mask, epsilon-greedy (``eps_sched`` float32 [>= T] on the device,
+    ``counter_base`` uint64 / int64 [1] on the device), gather.  Writes the staging rows ``hidden_out`` [>= T, E, J, H],
+    ``T_out`` int32 [T, E, J(,1)], ``P_out`` float32 [T, E, J(,1)] (all contiguous) and ``h_final`` [E*J, H]."""
+    lib = _native.load()
+    H, A = w_hh.shape[1], P_all.shape[-1]
+    io = _native.AgentEpisodeIO()
+    io.n_envs, io.T, io.J, io.H, io.A = int(n_envs), int(T), int(n_agents), H, A
+    io.greedy_only = 1 if greedy_only else 0
+    keep = []
+
+    def f32(t):
+        t = t.detach()
+        t = t if (t.dtype == torch.float32 and t.stride(-1) == 1) else t.float().contiguous()
+        keep.append(t)
+        return t
+
+    gi, P_all = f32(gi), f32(P_all)
+    io.gi, io.gi_ld = gi.data_ptr(), gi.stride(0)
+    io.P_all, io.p_ld = P_all.data_ptr(), P_all.stride(0)
+    if h0 is not None:
+        h0 = f32(h0).contiguous()
+        keep.append(h0)
+        io.h0 = h0.data_ptr()
+    w_hh, b_hh, W1 = f32(w_hh).contiguous(), f32(b_hh).contiguous(), f32(W1)
+    keep += [w_hh, b_hh]
+    io.w_hh, io.b_hh = w_hh.data_ptr(), b_hh.data_ptr()
+    io.W1, io.w1_ld = W1.data_ptr(), W1.stride(0)
+    b1, w2, b2 = f32(b1).contiguous(), f32(w2).reshape(-1).contiguous(), f32(b2).reshape(-1).contiguous()
+    keep += [b1, w2, b2]
+    io.b1, io.w2, io.b2 = b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
+    if avail is not None:
+        if avail.dtype not in (torch.int32, torch.int64):
+            avail = avail.to(torch.int32)
+        keep.append(avail)
+        io.avail, io.avail_elem_size = avail.data_ptr(), avail.element_size()
+        io.av_se, io.av_sj, io.av_sa = avail.stride(0), avail.stride(1), avail.stride(2)
+    if eps_sched is not None:
+        assert eps_sched.dtype == torch.float32 and eps_sched.numel() >= T and eps_sched.is_contiguous()
+        io.eps = eps_sched.data_ptr()
+    io.seed = int(seed) & (2 ** 64 - 1)
+    if counter_base is not None:
+        assert counter_base.dtype in (torch.int64, torch.uint64) and counter_base.numel() >= 1
+        io.counter_base = counter_base.data_ptr()
+    for name, t_, dt in (("hidden_out", hidden_out, torch.float32), ("T_out", T_out, torch.int32), ("P_out", P_out, torch.float32)):
+        assert t_.is_contiguous() and t_.dtype == dt and t_.device == gi.device, name
+    assert hidden_out.numel() >= T * n_envs * n_agents * H and T_out.numel() >= T * n_envs * n_agents and P_out.numel() >= T_out.numel()
+    io.hidden, io.T_out, io.P_out = hidden_out.data_ptr(), T_out.data_ptr(), P_out.data_ptr()
+    if h_final is not None:
+        assert h_final.is_contiguous() and h_final.dtype == torch.float32 and h_final.numel() == n_envs * n_agents * H
+        io.h_final = h_final.data_ptr()
+    with torch.cuda.device(gi.device):
+        _native.check(lib.macjd_agent_episode(ctypes.byref(io), _stream(gi)), "macjd_agent_episode")
+
+
 def gru_sequence_reference(gi: torch.Tensor, w_hh: torch.Tensor, b_hh: torch.Tensor,
                            h0: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Step-by-step GRU recurrence with stock torch ops (host tensors / numerics tests).

@@ -11,6 +11,7 @@
 """
 from __future__ import annotations
 
+import os
 from functools import partial
 from typing import Dict
 
@@ -311,12 +312,65 @@ class BatchedEpisodeRunner:
         self._graphs[n].replay()
         self.t_env += n
 
+    # ---- whole-episode launches: the agent's T steps as one kernel, the env's T steps as another ----
+    fused_rollout = os.environ.get("MACJD_FUSED_ROLLOUT", "1") != "0"
+
+    def fused_rollout_available(self) -> bool:
+        """The observation is static (so the agent's steps do not depend on the env's outputs), the MAC is the stock
+        RNNAgent on a HIP device at a size the episode kernel covers, and the env offers the many-step launch."""
+        if not (self.fused_rollout and self.hoist_static_obs and self.device.type == "cuda" and hasattr(self.env, "step_many")):
+            return False
+        agent = getattr(self.mac, "agent", None)
+        if agent is None or not hasattr(self.mac, "prepare_static_obs") or not next(agent.parameters()).is_cuda:
+            return False
+        from .. import ops
+        return (getattr(self.env, "kernel_flags", 0) == 0
+                and ops.agent_episode_supported(self.n_agents, agent.rnn_hidden_dim, agent.n_actions))
+
+    def rollout_fused(self, test_mode=False, n_steps=None):
+        """One episode batch (or its first ``n_steps`` steps) in THREE launches: ``ops.agent_episode`` (GRU cell + all-action
+        Q-head + epsilon-greedy selection for all steps: nothing the agent computes depends on the env's outputs while the
+        observation is static), ``env.step_many`` (all steps of all envs as independent work items + the counter
+        update).  Same staging rows, exploration draws (row, episode * (T + 1) + t + 1) and Monte-Carlo streams as the
+        step-by-step path; the hidden states / Q-values differ from it by the summation order of two matrix products
+        (~1e-7), which can flip an arg-max only on a near-tie."""
+        from .. import ops
+        T = self.episode_limit
+        n = T if n_steps is None else int(n_steps)
+        if not 1 <= n <= T:
+            raise ValueError(f"rollout_fused: n_steps must be in 1..{T}, got {n_steps}")
+        st, mac, env = self.stage, self.mac, self.env
+        E, J = self.batch_envs, self.n_agents
+        if getattr(self, "_eps_sched", None) is None:
+            self._eps_sched = torch.zeros(T, dtype=torch.float32, device=self.device)
+            self._ctr_base = torch.zeros(1, dtype=torch.int64, device=self.device)
+        if getattr(self, "_rdpj_steps", None) is None:
+            self._rdpj_steps = torch.zeros((T, E, 3), dtype=torch.float32, device=self.device)
+        sel = mac.action_selector
+        eps = np.zeros(T, dtype=np.float32)
+        for t in range(n):
+            eps[t] = sel.anneal(self.t_env + t, test_mode=test_mode)
+        self._eps_sched.copy_(torch.from_numpy(eps))
+        self.begin_episodes()                       # episode index, zero hidden state, env reset, static rows + inputs
+        self._ctr_base.fill_(self._ep * (T + 1))
+        params, gi = mac.static_inputs
+        a = mac.agent
+        l1, l2 = a.fc2_q_head[0], a.fc2_q_head[2]
+        ops.agent_episode(gi, params, None, a.rnn.weight_hh, a.rnn.bias_hh, l1.weight, l1.bias, l2.weight, l2.bias,
+                          E, J, n, self._avail, self._eps_sched, bool(test_mode), mac.select_seed, self._ctr_base,
+                          st["hidden_state"], st["actions_discrete"], st["actions_continuous"], h_final=mac.hidden_states)
+        env.step_many(st["actions_discrete"][:n], st["actions_continuous"][:n], st["reward"][:n], st["terminated"][:n],
+                      self._rdpj_steps[:n], rdpj_sum=self._rdpj_sum)
+        self.t_env += n
+
     def run(self, test_mode=False, store=True, sync_stats=True):
         """One batch of E episodes.  Returns the reference's ``run_info`` keys as means over the E
         episodes (one host sync at the very end; pass ``sync_stats=False`` to get 0-dim tensors)."""
         st = self.stage
         T, E, J = self.episode_limit, self.batch_envs, self.n_agents
-        if getattr(self, "_graph", None) is not None and not test_mode:
+        if self.fused_rollout_available():
+            self.rollout_fused(test_mode=test_mode)
+        elif getattr(self, "_graph", None) is not None and not test_mode:
             self.rollout_graphed()
         else:
             self.begin_episodes()

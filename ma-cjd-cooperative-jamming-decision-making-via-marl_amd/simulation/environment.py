@@ -277,6 +277,35 @@ class BatchedElectromagneticEnvironment:
             info["snr_no_jamming"] = self._snr_no
         return rew, (ter.view(torch.bool) if ter.dtype == torch.uint8 else ter), info
 
+    def step_many(self, actions_T: torch.Tensor, actions_P: torch.Tensor, out_reward: torch.Tensor,
+                  out_terminated: torch.Tensor, out_rdpj: torch.Tensor, rdpj_sum: Optional[torch.Tensor] = None) -> None:
+        """All n steps of an episode batch in ONE launch (+ a tiny one that advances the counters), given the actions of
+        all steps: ``actions_T`` int32 / ``actions_P`` float32 [n, E, J(,1)] contiguous (the runner's staging tensors);
+        ``out_reward`` float32 [n, E(,1)], ``out_terminated`` bool / uint8 [n, E(,1)], ``out_rdpj`` float32 [n, E, 3] —
+        all contiguous.  Legal because a step's outcome depends on the env's past only through the step counter (the
+        FSM's next state equals `detected`, core/radar.py:102-117) — see include/macjd.h, macjd_env_step_many; meant for
+        actions that do not depend on the env's outputs (static observation).  Philox uniforms, no pd / snr outputs."""
+        E, J = self.batch_envs, self.num_jammers
+        n = actions_T.shape[0]
+        for name, t, dt in (("actions_T", actions_T, torch.int32), ("actions_P", actions_P, torch.float32),
+                            ("out_reward", out_reward, torch.float32), ("out_rdpj", out_rdpj, torch.float32)):
+            if t.dtype != dt or not t.is_contiguous() or t.device != self.device:
+                raise ValueError(f"{name} must be a contiguous {dt} tensor on {self.device}")
+        if actions_T.numel() != n * E * J or actions_P.numel() != n * E * J or out_reward.numel() != n * E \
+                or out_terminated.numel() != n * E or out_rdpj.numel() != n * E * 3 or not out_terminated.is_contiguous():
+            raise ValueError("step_many: tensor sizes do not match [n, E, J] / [n, E] / [n, E, 3]")
+        if out_terminated.dtype not in (torch.uint8, torch.bool):
+            raise ValueError("out_terminated must be uint8 or bool")
+        io = self._fill_io(actions_T[0].view(E, J), actions_P[0].view(E, J), None, False, out_reward.view(-1)[:E],
+                           out_terminated.view(-1)[:E], False, None, rdpj_sum)
+        io.r_dpj = out_rdpj.data_ptr()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            _native.check(self._lib.macjd_env_step_many(self._handle.ptr, ctypes.byref(io), int(n), int(E * J), stream),
+                          "macjd_env_step_many")
+        io.r_dpj = self._r_dpj.data_ptr()
+        self._keep = (actions_T, actions_P, out_reward, out_terminated, out_rdpj)
+
     def time_step_kernel(self, actions_T: torch.Tensor, actions_P: torch.Tensor, iters: int,
                          uniforms: Optional[torch.Tensor] = None, want_info: bool = True) -> float:
         """bench.py helper: average milliseconds per env_step launch over ``iters`` back-to-back

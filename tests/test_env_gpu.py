@@ -254,6 +254,43 @@ def test_every_episode_draws_fresh_monte_carlo_values():
         assert whole.episode_index.cpu().tolist() == ora.episode.tolist()
 
 
+@pytest.mark.parametrize("name,E,n", [("3j4r", 777, 23), ("6j8r", 300, 7), ("2j2r_shipped", 64, 100)])
+def test_many_step_launch_equals_step_by_step(name, E, n):
+    """macjd_env_step_many: the n steps of an episode batch as ONE launch over n x E independent work items (the FSM's
+    next state does not depend on the previous one, core/radar.py:102-117, so given the actions of all steps the env-steps
+    are independent) == n single-step launches, bit for bit: rewards, terminated, (r_d, r_p, r_j) per step and summed,
+    final FSM state, step counters; also across an episode boundary of the counters and against the oracle."""
+    sc, _ = load_scenario(name)
+    R, J = sc.num_radars, sc.num_jammers
+    rng = np.random.default_rng(E + n)
+    Ts = np.stack([random_actions(rng, E, J, R, with_invalid=True)[0] for _ in range(n)])
+    Ps = rng.random((n, E, J)).astype(np.float32)
+    Td, Pd = torch.from_numpy(Ts).cuda(), torch.from_numpy(Ps).cuda()
+    one, many, ora = _env(sc, E, seed=17, env_offset=40), _env(sc, E, seed=17, env_offset=40), OracleEnv(sc, E, n_threads=4)
+    for rep in range(2):     # second repetition: another episode index
+        one.reset(); many.reset(); ora.reset()
+        rew1 = torch.zeros((n, E), device="cuda"); ter1 = torch.zeros((n, E), dtype=torch.uint8, device="cuda")
+        rd1 = torch.zeros((n, E, 3), device="cuda"); sum1 = torch.zeros((E, 3), device="cuda")
+        for t in range(n):
+            _, _, info = one.step(Td[t], Pd[t], out_reward=rew1[t], out_terminated=ter1[t], want_info=False, rdpj_sum=sum1)
+            rd1[t] = one._r_dpj
+            if t in (0, n - 1):
+                o = ora.step(Ts[t], Ps[t], seed=17, env_offset=40)
+                np.testing.assert_allclose(rew1[t].cpu().numpy(), o["reward"], rtol=0, atol=TOL_REWARD)
+                np.testing.assert_array_equal(one.track.cpu().numpy(), o["track"])
+            else:
+                ora.step_count += 1
+        rewn = torch.zeros((n, E, 1), device="cuda"); tern = torch.zeros((n, E, 1), dtype=torch.bool, device="cuda")
+        rdn = torch.zeros((n, E, 3), device="cuda"); sumn = torch.zeros((E, 3), device="cuda")
+        many.step_many(Td.view(n, E, J, 1), Pd.view(n, E, J, 1), rewn, tern, rdn, rdpj_sum=sumn)
+        assert torch.equal(rewn.view(n, E), rew1) and torch.equal(tern.view(n, E).to(torch.uint8), ter1)
+        assert torch.equal(rdn, rd1) and torch.equal(sumn, sum1)
+        assert torch.equal(many.track, one.track) and torch.equal(many.step_count, one.step_count)
+        assert int(many.step_count.min()) == n and torch.equal(many.episode_index, one.episode_index)
+    with pytest.raises(ValueError):
+        many.step_many(Td.to(torch.int64), Pd, rewn, tern, rdn)
+
+
 def test_reset_mask_and_outputs_into_caller_buffers():
     sc, _ = load_scenario("3j4r")
     R, J, E = sc.num_radars, sc.num_jammers, 300

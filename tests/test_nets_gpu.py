@@ -661,6 +661,88 @@ def test_graphed_rollout_equals_eager_rollout():
             assert torch.equal(a, b), k
 
 
+@pytest.mark.parametrize("scenario,per_env", [("3j4r", False), ("3j4r", True), ("6j8r", False), ("2j2r_shipped", False)])
+def test_fused_episode_rollout_vs_step_by_step(scenario, per_env):
+    """The whole episode batch in three launches (ops.agent_episode: GRU cell + all-action Q-head + epsilon-greedy for all
+    100 steps; env.step_many: all env steps as independent work items) against the step-by-step rollout with the same
+    weights, seeds and exploration counters.  Both paths use the same exploration draws and Monte-Carlo streams; the hidden
+    states differ by the summation order of the recurrent product (library GEMM vs MFMA chain), so: hidden states within
+    1e-5, the chosen actions identical except on near-ties (>= 99.5 % here), and wherever all agents of an env-step chose
+    the same actions the rewards / terminated flags are bit-identical.  Every stored hidden state and action is also
+    checked for self-consistency with stock torch ops (greedy pass: the chosen action's Q is the maximum within 1e-5)."""
+    from macjd_amd import ops
+    from macjd_amd.core.mac import BasicMAC
+    from macjd_amd.runners.episode_runner import BatchedEpisodeRunner
+    from macjd_amd.scenario import ScenarioBatch
+    from macjd_amd.simulation.environment import BatchedElectromagneticEnvironment
+    from macjd_amd.utils.replay_buffer import EpisodeReplayBuffer
+    sc, g_ = load_scenario(scenario)
+    E = 200   # not a multiple of 16: the last workgroup is ragged
+    def build(fused):
+        if per_env:
+            batch = ScenarioBatch.randomized(json.loads(str(g_["scenario_json"])), E, seed=8)
+            env = BatchedElectromagneticEnvironment(scenario_batch=batch, device=DEV, seed=5)
+        else:
+            env = BatchedElectromagneticEnvironment(scenario=sc, batch_envs=E, device=DEV, seed=5)
+        info = env.get_env_info()
+        d = dict(J=info["n_agents"], A=info["n_actions"], S=info["state_shape"], H=64)
+        args = _gpu_args(d, episode_limit=info["episode_limit"], buffer_size=2 * E, epsilon_start=0.3, epsilon_anneal_time=500)
+        args.env_info = info
+        torch.manual_seed(3)
+        with quiet():
+            mac = BasicMAC(info["obs_shape"], args)
+            with torch.no_grad():   # spread the Q-values: fewer near-ties between the two summation orders
+                for p_ in mac.agent.fc2_q_head.parameters():
+                    p_.mul_(3.0)
+            mac.cuda()
+            buf = EpisodeReplayBuffer(args)
+        r = BatchedEpisodeRunner(env, mac, buf, args)
+        r.fused_rollout = fused
+        assert r.fused_rollout_available() == fused
+        return r, buf, mac, args
+    rf, bf, mf, args = build(True)
+    rs, bs, ms, _ = build(False)
+    for ep in range(2):
+        i_f = rf.run(sync_stats=True)
+        i_s = rs.run(sync_stats=True)
+    assert rf.t_env == rs.t_env == 200 and mf.action_selector.epsilon == pytest.approx(ms.action_selector.epsilon)
+    B = {k: (bf.buffers[k], bs.buffers[k]) for k in bf.buffers}
+    np.testing.assert_allclose(B["hidden_state"][0].cpu().numpy(), B["hidden_state"][1].cpu().numpy(), atol=2e-5, rtol=0)
+    same = (B["actions_discrete"][0] == B["actions_discrete"][1])                    # [N, T, J, 1]
+    assert float(same.float().mean()) > 0.995
+    agree = same.all(dim=2).squeeze(-1)                                              # [N, T]: all agents agree
+    pa, pb = B["actions_continuous"]
+    assert torch.equal(pa[same], pb[same])
+    assert torch.equal(B["reward"][0].squeeze(-1)[agree], B["reward"][1].squeeze(-1)[agree])
+    assert torch.equal(B["terminated"][0], B["terminated"][1]) and torch.equal(B["filled"][0], B["filled"][1])
+    for k in ("state", "obs", "avail_actions"):
+        assert torch.equal(*B[k]), k
+    assert torch.allclose(mf.hidden_states, ms.hidden_states, atol=2e-5)
+    for k in ("episode_return", "avg_r_d", "avg_r_p", "avg_r_j", "avg_power_overall"):
+        assert i_f[k] == pytest.approx(i_s[k], rel=2e-3, abs=2e-3), k
+    # self-consistency of a GREEDY fused episode with stock torch ops on the stored rows
+    rf.run(test_mode=True, store=False, sync_stats=False)
+    st = rf.stage
+    T, J, H = rf.episode_limit, rf.n_agents, 64
+    a = mf.agent
+    with torch.no_grad():
+        obs = st["obs"][0].reshape(E * J, -1)
+        P = a.actor(obs)
+        x = torch.relu(a.fc1(obs))
+        h = torch.zeros(E * J, H, device=DEV)
+        worst = 0.0
+        for t in range(T):
+            h = a.rnn(x, h)
+            np.testing.assert_allclose(st["hidden_state"][t].reshape(E * J, H).cpu().numpy(), h.cpu().numpy(), atol=2e-5, rtol=0)
+            h = st["hidden_state"][t].reshape(E * J, H)      # follow the stored trajectory
+            q = a.q_values_all_actions(h, P)
+            ch = st["actions_discrete"][t].reshape(E * J).long()
+            gap = q.max(dim=1).values - q.gather(1, ch.view(-1, 1)).squeeze(1)
+            worst = max(worst, float(gap.max()))
+            assert torch.equal(st["actions_continuous"][t].reshape(E * J), P.gather(1, ch.view(-1, 1)).squeeze(1))
+        assert worst <= 1e-5 * max(1.0, float(q.abs().max())), worst
+
+
 @pytest.mark.parametrize("per_env", [False, True])
 def test_static_observation_hoist_gives_identical_buffers(per_env):
     """The observation never changes within an episode (env.observation_is_static), so the batched runner has the MAC
