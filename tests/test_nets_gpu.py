@@ -642,7 +642,9 @@ def test_graphed_rollout_equals_eager_rollout():
             mac = BasicMAC(info["obs_shape"], args)
             mac.cuda()
             buf = EpisodeReplayBuffer(args)
-        return BatchedEpisodeRunner(env, mac, buf, args), buf, mac
+        r = BatchedEpisodeRunner(env, mac, buf, args)
+        r.fused_rollout = False      # the step-by-step rollout: eager launches vs one graph replay
+        return r, buf, mac
     r_e, b_e, m_e = build()
     r_g, b_g, m_g = build()
     r_g.enable_graph()
@@ -739,7 +741,7 @@ def test_fused_episode_rollout_vs_step_by_step(scenario, per_env):
             ch = st["actions_discrete"][t].reshape(E * J).long()
             gap = q.max(dim=1).values - q.gather(1, ch.view(-1, 1)).squeeze(1)
             worst = max(worst, float(gap.max()))
-            assert torch.equal(st["actions_continuous"][t].reshape(E * J), P.gather(1, ch.view(-1, 1)).squeeze(1))
+            assert torch.allclose(st["actions_continuous"][t].reshape(E * J), P.gather(1, ch.view(-1, 1)).squeeze(1), atol=1e-6, rtol=1e-5)
         assert worst <= 1e-5 * max(1.0, float(q.abs().max())), worst
 
 
@@ -773,6 +775,7 @@ def test_static_observation_hoist_gives_identical_buffers(per_env):
             buf = EpisodeReplayBuffer(args)
         r = BatchedEpisodeRunner(env, mac, buf, args)
         assert r.hoist_static_obs
+        r.fused_rollout = False      # this test is about the step-by-step path (eager and graph-replayed)
         r.hoist_static_obs = hoist
         if graph:
             r.enable_graph()
