@@ -442,6 +442,28 @@ typedef struct macjd_agent_episode_io {
 int macjd_agent_episode_supported(int32_t J, int32_t H, int32_t A);
 int macjd_agent_episode(const macjd_agent_episode_io* io, void* hip_stream);
 
+/*
+ * Double-DQN target values straight from the unrolled hidden states (reference core/qmix.py:138-147): for every row n
+ *   a* = argmax_a Q_eval(h_e[n], a, P_e[n,a])   (no availability mask there, qmix.py:141-142)
+ *   out[n] = Q_target(h_t[n], a*, P_t[n,a*])
+ * in ONE launch: both Q-head base products W1[:, :H] h + b1 on the matrix cores (exact f32), both all-action Q-heads,
+ * arg-max and gather.  Replaces two library GEMMs + two macjd_qhead_select launches behind the learner's scan.
+ * h_e / h_t [n, H] (the same tensor when the agent body is shared), P_e / P_t [n, A].  Supported: H = 64, A in {5, 9, 17}.
+ */
+typedef struct macjd_doubleq_io {
+    int64_t n_rows;
+    int32_t H, A;
+    const float* h_e; int64_t he_ld;  const float* h_t; int64_t ht_ld;
+    const float* P_e; int64_t pe_ld;  const float* P_t; int64_t pt_ld;
+    const float* W1_e; int64_t w1e_ld; const float* b1_e; const float* w2_e; const float* b2_e;   /* eval fc2_q_head */
+    const float* W1_t; int64_t w1t_ld; const float* b1_t; const float* w2_t; const float* b2_t;   /* target fc2_q_head */
+    float* out;              /* [n] */
+    int64_t* argmax_out;     /* optional [n] */
+} macjd_doubleq_io;
+
+int macjd_qhead_double_q_supported(int32_t H, int32_t A);
+int macjd_qhead_double_q(const macjd_doubleq_io* io, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

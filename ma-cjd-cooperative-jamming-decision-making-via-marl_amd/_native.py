@@ -28,6 +28,7 @@ EXPORTS = [
     "macjd_linear_wgrad", "macjd_linear_wgrad_workspace_floats", "macjd_linear_wgrad_many", "macjd_qhead_input", "macjd_layernorm_forward", "macjd_layernorm_param_grad", "macjd_gru_gates", "macjd_rowdot", "macjd_splitrelu_backward",
     "macjd_mixer_fused_supported", "macjd_mixer_fused_forward", "macjd_mixer_fused_backward",
     "macjd_agent_episode_supported", "macjd_agent_episode", "macjd_env_step_many",
+    "macjd_qhead_double_q_supported", "macjd_qhead_double_q",
 ]
 
 
@@ -128,6 +129,18 @@ class AgentEpisodeIO(ctypes.Structure):
         ("av_se", ctypes.c_int64), ("av_sj", ctypes.c_int64), ("av_sa", ctypes.c_int64),
         ("eps", ctypes.c_void_p), ("seed", ctypes.c_uint64), ("counter_base", ctypes.c_void_p),
         ("hidden", ctypes.c_void_p), ("T_out", ctypes.c_void_p), ("P_out", ctypes.c_void_p), ("h_final", ctypes.c_void_p),
+    ]
+
+
+class DoubleQIO(ctypes.Structure):
+    """ctypes mirror of ``macjd_doubleq_io`` (include/macjd_nets.h)."""
+    _fields_ = [
+        ("n_rows", ctypes.c_int64), ("H", ctypes.c_int32), ("A", ctypes.c_int32),
+        ("h_e", ctypes.c_void_p), ("he_ld", ctypes.c_int64), ("h_t", ctypes.c_void_p), ("ht_ld", ctypes.c_int64),
+        ("P_e", ctypes.c_void_p), ("pe_ld", ctypes.c_int64), ("P_t", ctypes.c_void_p), ("pt_ld", ctypes.c_int64),
+        ("W1_e", ctypes.c_void_p), ("w1e_ld", ctypes.c_int64), ("b1_e", ctypes.c_void_p), ("w2_e", ctypes.c_void_p), ("b2_e", ctypes.c_void_p),
+        ("W1_t", ctypes.c_void_p), ("w1t_ld", ctypes.c_int64), ("b1_t", ctypes.c_void_p), ("w2_t", ctypes.c_void_p), ("b2_t", ctypes.c_void_p),
+        ("out", ctypes.c_void_p), ("argmax_out", ctypes.c_void_p),
     ]
 
 
@@ -283,6 +296,10 @@ def load() -> ctypes.CDLL:
     for name in ("macjd_mixer_tail_forward", "macjd_mixer_tail_backward"):
         getattr(lib, name).restype = ctypes.c_int
         getattr(lib, name).argtypes = [ctypes.POINTER(MixerIO), ctypes.c_void_p]
+    lib.macjd_qhead_double_q_supported.restype = ctypes.c_int
+    lib.macjd_qhead_double_q_supported.argtypes = [ctypes.c_int32] * 2
+    lib.macjd_qhead_double_q.restype = ctypes.c_int
+    lib.macjd_qhead_double_q.argtypes = [ctypes.POINTER(DoubleQIO), ctypes.c_void_p]
     lib.macjd_agent_episode_supported.restype = ctypes.c_int
     lib.macjd_agent_episode_supported.argtypes = [ctypes.c_int32] * 3
     lib.macjd_agent_episode.restype = ctypes.c_int

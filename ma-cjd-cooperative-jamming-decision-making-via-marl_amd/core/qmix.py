@@ -298,6 +298,7 @@ class QMixLearner:
         # ONE scan and ONE actor chain serve both networks; only the Q-heads differ.
         shared = self._body_is_shared()
         body = macs[1].agent   # the network whose body is evaluated when shared
+        fused_dq = os.environ.get("MACJD_FUSED_DOUBLEQ", "1") != "0" and ops.qhead_double_q_fused_supported(rows, H, A)
 
         # Two streams inside the (captured) update (kernel timeline: scripts/timeline_update.py; the measured
         # alternatives are tabulated in DESIGN.md 4.8):
@@ -322,11 +323,17 @@ class QMixLearner:
                     gis = [m.agent.gru_input_transform(rows).view(B, T1, J, 3 * H) for m in macs]
                 h_alls = ops.gru_sequence_multi(gis, [m.agent.rnn.weight_hh for m in macs],
                                                 [m.agent.rnn.bias_hh for m in macs])
+            if fused_dq:   # the Double-DQN launch takes the hidden states themselves (its base products run on MFMA)
+                return [h.reshape(n, H) for h in h_alls]
             return [F.linear(h.reshape(n, H), hd[0][:, :H], m.agent.fc2_q_head[0].bias)
                     for m, h, hd in zip(macs, h_alls, heads)]
 
         def double_q(bases, params):
-            # a* = argmax_a Q_eval (no mask, qmix.py:138-143), Q_target(a*) (qmix.py:147): two launches, [B,T+1,J]
+            # a* = argmax_a Q_eval (no mask, qmix.py:138-143), Q_target(a*) (qmix.py:147), [B,T+1,J]: one launch from the
+            # hidden states, or two Q-head launches on library-GEMM bases
+            if fused_dq:
+                hd4 = [(hd[0], m.agent.fc2_q_head[0].bias, hd[1], hd[2]) for m, hd in zip(macs, heads)]
+                return ops.qhead_double_q_from_h(bases[1], params[1], hd4[1], bases[0], params[0], hd4[0], H, A).view(B, T1, J)
             return ops.qhead_double_q(bases[1], params[1], heads[1], bases[0], params[0], heads[0], H, A).view(B, T1, J)
 
         def eval_forward():

@@ -262,7 +262,154 @@ __global__ void __launch_bounds__(256) agent_episode_kernel(const macjd_agent_ep
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Double-DQN target values from hidden states (include/macjd_nets.h, macjd_doubleq_io): workgroup = 16 rows; wave w
+// computes the Q-head base columns [16w, 16w+16) of BOTH networks (8 quads of MFMA each), then wave 0 evaluates the eval
+// head and wave 1 the target head for all actions (lane = (row, quarter of the 64 units), as in agent_episode_kernel),
+// the arg-max crosses through 64 bytes of LDS.
+template <int A>
+__global__ void __launch_bounds__(256) qhead_double_q_kernel(const macjd_doubleq_io io) {
+    __shared__ __attribute__((aligned(16))) float Hs[2][16 * EP_LD];    // h rows of the eval / target unroll
+    __shared__ __attribute__((aligned(16))) float Bs[2][16 * EP_LD];    // base of the eval / target head
+    __shared__ float Wq[2][(A + 2) * EP_H];
+    __shared__ int amax_s[16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    const int64_t n0 = (int64_t)blockIdx.x * 16;
+    const bool same_h = (io.h_e == io.h_t) && (io.he_ld == io.ht_ld);
+    // weight fragments + this lane's bias of both heads
+    f32x4 Be[EP_KQ], Bt[EP_KQ];
+#pragma unroll
+    for (int Q = 0; Q < EP_KQ; ++Q) {
+        Be[Q] = *reinterpret_cast<const f32x4_u*>(io.W1_e + (int64_t)(16 * wave + li) * io.w1e_ld + 16 * Q + 4 * g);
+        Bt[Q] = *reinterpret_cast<const f32x4_u*>(io.W1_t + (int64_t)(16 * wave + li) * io.w1t_ld + 16 * Q + 4 * g);
+    }
+    const int u = 16 * wave + li;
+    const float b1e = io.b1_e[u], b1t = io.b1_t[u];
+    // Q-head roles: wave 0 = eval head, wave 1 = target head; lane = (row qr, quarter qq)
+    const int qr = lane & 15, qq = lane >> 4;
+    const int64_t nq = (n0 + qr < io.n_rows) ? n0 + qr : io.n_rows - 1;
+    float pv[A];
+    {
+        const float* prow = (wave == 1) ? io.P_t + nq * io.pt_ld : io.P_e + nq * io.pe_ld;
+#pragma unroll
+        for (int a = 0; a < A; ++a) pv[a] = prow[a];
+    }
+    const float b2 = (wave == 1) ? io.b2_t[0] : io.b2_e[0];
+    // h rows -> LDS (float4 pieces when aligned; rows past n: the last row, never stored)
+    for (int idx = threadIdx.x; idx < 2 * 16 * (EP_H / 4); idx += 256) {
+        const int which = idx / (16 * (EP_H / 4)), rem = idx - which * 16 * (EP_H / 4);
+        const int row = rem / (EP_H / 4), c4 = rem - row * (EP_H / 4);
+        if (which == 1 && same_h) continue;
+        const int64_t nn = (n0 + row < io.n_rows) ? n0 + row : io.n_rows - 1;
+        const float* src = (which ? io.h_t + nn * io.ht_ld : io.h_e + nn * io.he_ld) + 4 * c4;
+        *reinterpret_cast<f32x4*>(&Hs[which][row * EP_LD + 4 * c4]) = *reinterpret_cast<const f32x4_u*>(src);
+    }
+    for (int idx = threadIdx.x; idx < 2 * (A + 2) * EP_H; idx += 256) {
+        const int which = idx / ((A + 2) * EP_H), rem = idx - which * (A + 2) * EP_H;
+        const int a = rem / EP_H, uu = rem - a * EP_H;
+        const float* W1 = which ? io.W1_t : io.W1_e;
+        const int64_t ld = which ? io.w1t_ld : io.w1e_ld;
+        Wq[which][rem] = (a <= A) ? W1[(int64_t)uu * ld + EP_H + a] : (which ? io.w2_t : io.w2_e)[uu];
+    }
+    __syncthreads();
+    {
+        f32x4 ae = f32x4{0.f, 0.f, 0.f, 0.f}, at = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* he = &Hs[0][li * EP_LD + 4 * g];
+        const float* ht = &Hs[same_h ? 0 : 1][li * EP_LD + 4 * g];
+#pragma unroll
+        for (int Q = 0; Q < EP_KQ; ++Q) {
+            const f32x4 xe = *reinterpret_cast<const f32x4*>(he + 16 * Q);
+            const f32x4 xt = *reinterpret_cast<const f32x4*>(ht + 16 * Q);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                ae = __builtin_amdgcn_mfma_f32_16x16x4f32(xe[jj], Be[Q][jj], ae, 0, 0, 0);
+                at = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[jj], Bt[Q][jj], at, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Bs[0][(4 * g + r) * EP_LD + u] = ae[r] + b1e;
+            Bs[1][(4 * g + r) * EP_LD + u] = at[r] + b1t;
+        }
+    }
+    __syncthreads();
+    float q[A];
+    if (wave < 2) {   // wave-uniform
+        const float* wq = Wq[wave];
+#pragma unroll
+        for (int a = 0; a < A; ++a) q[a] = 0.0f;
+        const float* brow = &Bs[wave][qr * EP_LD + 16 * qq];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + 4 * k4);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int uu = 16 * qq + 4 * k4 + kk;
+                const float wp = wq[A * EP_H + uu], w2u = wq[(A + 1) * EP_H + uu];
+#pragma unroll
+                for (int a = 0; a < A; ++a) {
+                    float v = b4[kk] + wq[a * EP_H + uu];
+                    v = fmaf(pv[a], wp, v);
+                    v = fmaxf(v, 0.0f);
+                    q[a] = fmaf(v, w2u, q[a]);
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            q[a] += __shfl_xor(q[a], 16, 64);
+            q[a] += __shfl_xor(q[a], 32, 64);
+            q[a] += b2;
+        }
+        if (wave == 0 && qq == 0) {   // first maximum of the unmasked eval values (qmix.py:138-143)
+            int am = 0;
+            float aq = q[0];
+#pragma unroll
+            for (int a = 1; a < A; ++a)
+                if (q[a] > aq) { aq = q[a]; am = a; }
+            amax_s[qr] = am;
+            if (io.argmax_out && n0 + qr < io.n_rows) io.argmax_out[n0 + qr] = am;
+        }
+    }
+    __syncthreads();
+    if (wave == 1 && qq == 0 && n0 + qr < io.n_rows) {   // qmix.py:147
+        const int am = amax_s[qr];
+        float gq = 0.0f;
+#pragma unroll
+        for (int a = 0; a < A; ++a) gq = (a == am) ? q[a] : gq;
+        io.out[n0 + qr] = gq;
+    }
+}
+
 }  // namespace macjd
+
+extern "C" int macjd_qhead_double_q_supported(int32_t H, int32_t A) {
+    return (H == macjd::EP_H) && (A == 5 || A == 9 || A == 17);
+}
+
+extern "C" int macjd_qhead_double_q(const macjd_doubleq_io* io, void* hip_stream) {
+    using namespace macjd;
+    if (!io) return set_err(MACJD_EINVAL, "%s", "macjd_qhead_double_q: NULL io");
+    if (!macjd_qhead_double_q_supported(io->H, io->A))
+        return set_err(MACJD_EUNSUPPORTED, "%s", "macjd_qhead_double_q: unsupported H / A");
+    if (io->n_rows < 0 || !io->h_e || !io->h_t || !io->P_e || !io->P_t || !io->W1_e || !io->b1_e || !io->w2_e || !io->b2_e ||
+        !io->W1_t || !io->b1_t || !io->w2_t || !io->b2_t || !io->out)
+        return set_err(MACJD_EINVAL, "%s", "macjd_qhead_double_q: bad n_rows or NULL pointer");
+    if (io->he_ld < io->H || io->ht_ld < io->H || io->pe_ld < io->A || io->pt_ld < io->A || io->w1e_ld < io->H + io->A + 1 ||
+        io->w1t_ld < io->H + io->A + 1)
+        return set_err(MACJD_EINVAL, "%s", "macjd_qhead_double_q: row stride smaller than the row");
+    if (io->n_rows == 0) return MACJD_OK;
+    const dim3 grid((unsigned)((io->n_rows + 15) / 16)), block(256);
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (io->A == 5) hipLaunchKernelGGL((qhead_double_q_kernel<5>), grid, block, 0, s, *io);
+    else if (io->A == 9) hipLaunchKernelGGL((qhead_double_q_kernel<9>), grid, block, 0, s, *io);
+    else hipLaunchKernelGGL((qhead_double_q_kernel<17>), grid, block, 0, s, *io);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_qhead_double_q: %s", hipGetErrorString(err));
+    return MACJD_OK;
+}
 
 extern "C" int macjd_agent_episode_supported(int32_t J, int32_t H, int32_t A) {
     return (H == macjd::EP_H) && (J == 2 || J == 3 || J == 6) && (A == 5 || A == 9 || A == 17);

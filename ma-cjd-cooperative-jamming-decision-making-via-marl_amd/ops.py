@@ -91,6 +91,47 @@ def qhead_double_q(base_eval, P_eval, head_eval, base_tgt, P_tgt, head_tgt, H: i
     return out
 
 
+def qhead_double_q_fused_supported(h, H: int, A: int) -> bool:
+    return h.is_cuda and bool(_native.load().macjd_qhead_double_q_supported(int(H), int(A)))
+
+
+def qhead_double_q_from_h(h_eval, P_eval, head_eval, h_tgt, P_tgt, head_tgt, H: int, A: int, want_argmax: bool = False):
+    """Double-DQN target values [N] straight from the unrolled hidden states, ONE launch (csrc/macjd_episode.hip,
+    qhead_double_q_kernel): both Q-head base products on the matrix cores, both all-action Q-heads, unmasked arg-max of
+    the eval head, gather from the target head (reference core/qmix.py:138-147).  ``head_* = (W1 [H, H+A+1], b1 [H],
+    w2, b2)`` of each network's fc2_q_head; h_* [N, H]; P_* [N, A]."""
+    lib = _native.load()
+    keep = []
+
+    def c(t):
+        t = t.detach()
+        t = t if (t.dtype == torch.float32 and t.stride(-1) == 1) else t.float().contiguous()
+        keep.append(t)
+        return t
+
+    h_e, h_t, P_e, P_t = c(h_eval), c(h_tgt), c(P_eval), c(P_tgt)
+    N = h_e.shape[0]
+    io = _native.DoubleQIO()
+    io.n_rows, io.H, io.A = N, H, A
+    io.h_e, io.he_ld, io.h_t, io.ht_ld = h_e.data_ptr(), h_e.stride(0), h_t.data_ptr(), h_t.stride(0)
+    io.P_e, io.pe_ld, io.P_t, io.pt_ld = P_e.data_ptr(), P_e.stride(0), P_t.data_ptr(), P_t.stride(0)
+    for tag, head in (("e", head_eval), ("t", head_tgt)):
+        W1, b1 = c(head[0]), c(head[1]).contiguous()
+        w2, b2 = c(head[2]).reshape(-1).contiguous(), c(head[3]).reshape(-1).contiguous()
+        keep += [b1, w2, b2]
+        setattr(io, f"W1_{tag}", W1.data_ptr()); setattr(io, f"w1{tag}_ld", W1.stride(0))
+        setattr(io, f"b1_{tag}", b1.data_ptr()); setattr(io, f"w2_{tag}", w2.data_ptr()); setattr(io, f"b2_{tag}", b2.data_ptr())
+    out = torch.empty(N, dtype=torch.float32, device=h_e.device)
+    io.out = out.data_ptr()
+    am = None
+    if want_argmax:
+        am = torch.empty(N, dtype=torch.int64, device=h_e.device)
+        io.argmax_out = am.data_ptr()
+    with torch.cuda.device(h_e.device):
+        _native.check(lib.macjd_qhead_double_q(ctypes.byref(io), _stream(h_e)), "macjd_qhead_double_q")
+    return (out, am) if want_argmax else out
+
+
 def qhead_select(base, P_all, W1, w2, b2, H: int, A: int, n_agents: int, avail: Optional[torch.Tensor],
                  epsilon: float, greedy_only: bool, seed: int, counter: int, want_q: bool = False,
                  eps_dev: Optional[torch.Tensor] = None, counter_dev: Optional[torch.Tensor] = None,

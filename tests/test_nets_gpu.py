@@ -89,6 +89,44 @@ def test_double_q_helper_equals_argmax_gather():
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("tag", ["3j4r_h64", "6j8r_h64"])
+@pytest.mark.parametrize("N", [9696, 37])
+def test_double_q_from_hidden_states_kernel(tag, N):
+    """One launch from the hidden states (base products on MFMA, both all-action Q-heads, arg-max, gather) == the
+    NumPy oracle's per-action loop (pinned on G3) and the two-launch form on library-GEMM bases: arg-max identical except
+    on near-ties, values within 1e-5."""
+    from macjd_amd import ops
+    from macjd_amd.core.networks import RNNAgent
+    g, d = load(tag)
+    args = _gpu_args(d)
+    H, A = d["H"], d["A"]
+    torch.manual_seed(1)
+    with quiet():
+        ae, at = RNNAgent(d["S"], args).to(DEV), RNNAgent(d["S"], args).to(DEV)
+    ae.load_state_dict(sd_from(g, "agent."))
+    rng = np.random.default_rng(N)
+    h_e = torch.tensor(0.7 * rng.standard_normal((N, H)), dtype=torch.float32, device=DEV)
+    h_t = torch.tensor(0.7 * rng.standard_normal((N, H)), dtype=torch.float32, device=DEV)
+    P_e = torch.tensor(rng.random((N, A)), dtype=torch.float32, device=DEV)
+    P_t = torch.tensor(rng.random((N, A)), dtype=torch.float32, device=DEV)
+    heads = [(a.fc2_q_head[0].weight, a.fc2_q_head[0].bias, a.fc2_q_head[2].weight, a.fc2_q_head[2].bias) for a in (ae, at)]
+    assert ops.qhead_double_q_fused_supported(h_e, H, A)
+    with torch.no_grad():
+        out, am = ops.qhead_double_q_from_h(h_e, P_e, heads[0], h_t, P_t, heads[1], H, A, want_argmax=True)
+        same, am2 = ops.qhead_double_q_from_h(h_e, P_e, heads[0], h_e, P_e, heads[0], H, A, want_argmax=True)   # shared inputs
+    sd_e = {k: v.cpu().numpy() for k, v in ae.state_dict().items()}
+    sd_t = {k: v.cpu().numpy() for k, v in at.state_dict().items()}
+    q_e = nets_oracle.q_all_actions(sd_e, h_e.cpu().numpy(), P_e.cpu().numpy())
+    q_t = nets_oracle.q_all_actions(sd_t, h_t.cpu().numpy(), P_t.cpu().numpy())
+    am_ref = q_e.argmax(axis=1)
+    am_np = am.cpu().numpy()
+    tie = np.take_along_axis(q_e, am_ref[:, None], 1)[:, 0] - np.take_along_axis(q_e, am_np[:, None], 1)[:, 0]
+    assert (tie <= 1e-5).all() and (am_np == am_ref).mean() > 0.999
+    np.testing.assert_allclose(out.cpu().numpy(), np.take_along_axis(q_t, am_np[:, None], 1)[:, 0], atol=TOL, rtol=0)
+    np.testing.assert_allclose(same.cpu().numpy(), q_e.max(axis=1), atol=TOL, rtol=0)
+    assert torch.equal(am2, am)
+
+
 def test_fused_selection_writes_into_caller_rows():
     """out_T32 / out_P: the select kernel stores the chosen actions into caller-provided [E,J,1] rows (the runner's
     staging tensors) — same values as the default agent-major scratch outputs."""
