@@ -77,7 +77,8 @@ int macjd_qhead_select(const macjd_qhead_io* io, void* hip_stream);
  * H must be 64 or 128.
  */
 typedef struct macjd_gru_io {
-    int32_t n_nets, B, T, J, H, reserved;   /* n_nets = 1 or 2 */
+    int32_t n_nets, B, T, J, H, reserved;   /* n_nets = 1 or 2; reserved != 0 ("gi_static"): gi is [B,1,J,3H], the
+                                               same input transform at every step (static observation) */
     const float* gi[2];    /* [B,T,J,3H] */
     const float* w_hh[2];  /* rnn.weight_hh [3H,H] row-major */
     const float* b_hh[2];  /* rnn.bias_hh [3H] */

@@ -299,6 +299,17 @@ class QMixLearner:
         shared = self._body_is_shared()
         body = macs[1].agent   # the network whose body is evaluated when shared
         fused_dq = os.environ.get("MACJD_FUSED_DOUBLEQ", "1") != "0" and ops.qhead_double_q_fused_supported(rows, H, A)
+        # Static observations (the replay buffer knows: every stored episode came from an env whose observation does not
+        # change within an episode): everything of the agent that reads only the observation — the fc1 -> W_ih input
+        # transform and the actor chain — is evaluated on the B * J step-0 rows instead of on all B * (T + 1) * J rows;
+        # the scan takes the one input transform per sequence at every step.
+        obs_static = bool(getattr(self, "_g_obs_static", False))
+        rows_s = st["obs"][:, 0].reshape(B * J, -1) if obs_static else rows
+        Tg = 1 if obs_static else T1
+
+        def actor_all(agent):
+            p = agent.actor_forward(rows_s)                                                    # networks.py:127
+            return p.view(B, 1, J, A).expand(B, T1, J, A).reshape(n, A) if obs_static else p
 
         # Two streams inside the (captured) update (kernel timeline: scripts/timeline_update.py; the measured
         # alternatives are tabulated in DESIGN.md 4.8):
@@ -310,19 +321,20 @@ class QMixLearner:
         # Autograd only ever sees this stream.  Forks taken from a forked stream crash hipStreamEndCapture (ROCm 7.2):
         # every fork hangs off the capture's origin stream.  MACJD_UPDATE_STREAMS=1 runs everything on one stream.
         def scan_chain():
+            ns = T1 if obs_static else None
             if shared:
-                gis = [body.gru_input_transform(rows).view(B, T1, J, 3 * H)]                   # networks.py:100
-                h = ops.gru_sequence_multi(gis, [body.rnn.weight_hh], [body.rnn.bias_hh])[0]     # h_0 = 0, qmix.py:241
+                gis = [body.gru_input_transform(rows_s).view(B, Tg, J, 3 * H)]                 # networks.py:100
+                h = ops.gru_sequence_multi(gis, [body.rnn.weight_hh], [body.rnn.bias_hh], n_steps=ns)[0]   # h_0 = 0, qmix.py:241
                 h_alls = [h, h]
             else:
                 a0, a1 = macs[0].agent, macs[1].agent
                 if rows.is_cuda and a0.fused_gi and a1.fused_gi and not torch.is_grad_enabled():
                     # fc1 -> ReLU -> W_ih of both controllers: one launch of the dense-chain kernel
-                    gis = [g.view(B, T1, J, 3 * H) for g in ops.mlp_forward_pair(rows, a0.gi_layers(), rows, a1.gi_layers())]
+                    gis = [g.view(B, Tg, J, 3 * H) for g in ops.mlp_forward_pair(rows_s, a0.gi_layers(), rows_s, a1.gi_layers())]
                 else:
-                    gis = [m.agent.gru_input_transform(rows).view(B, T1, J, 3 * H) for m in macs]
+                    gis = [m.agent.gru_input_transform(rows_s).view(B, Tg, J, 3 * H) for m in macs]
                 h_alls = ops.gru_sequence_multi(gis, [m.agent.rnn.weight_hh for m in macs],
-                                                [m.agent.rnn.bias_hh for m in macs])
+                                                [m.agent.rnn.bias_hh for m in macs], n_steps=ns)
             if fused_dq:   # the Double-DQN launch takes the hidden states themselves (its base products run on MFMA)
                 return [h.reshape(n, H) for h in h_alls]
             return [F.linear(h.reshape(n, H), hd[0][:, :H], m.agent.fc2_q_head[0].bias)
@@ -351,9 +363,9 @@ class QMixLearner:
             ts.wait_stream(origin)                                                              # fork
             with torch.cuda.stream(ts), torch.no_grad():
                 bases = scan_chain()
-                p_target = None if shared else macs[0].agent.actor_forward(rows)               # networks.py:127
+                p_target = None if shared else actor_all(macs[0].agent)
             with torch.no_grad():
-                p_eval = body.actor_forward(rows)
+                p_eval = actor_all(body)
             eval_q_tot = eval_forward()
             with torch.no_grad():
                 # unfused mixer: its state-only half (LayerNorm + hyper-networks) runs here, before the join; the fused
@@ -367,8 +379,8 @@ class QMixLearner:
         else:
             with torch.no_grad():
                 bases = scan_chain()
-                p_eval = body.actor_forward(rows)
-                params = [p_eval if shared else macs[0].agent.actor_forward(rows), p_eval]
+                p_eval = actor_all(body)
+                params = [p_eval if shared else actor_all(macs[0].agent), p_eval]
                 hyper = None if self.target_qmix_net.fused_available(st["state"]) else self.target_qmix_net.hyper_outputs(st["state"])
                 target_q_tot = self.target_qmix_net(double_q(bases, params), st["state"], hyper=hyper)
             eval_q_tot = eval_forward()
@@ -445,6 +457,8 @@ class QMixLearner:
         if self.device.type != "cuda":
             raise RuntimeError("enable_graphs needs the learner on a HIP device")
         self._g_buffer, self._g_B, self._g_T = buffer, int(batch_size), int(buffer.episode_limit)
+        # static observations in every stored episode (see _forward_backward_full): baked into the captured launches
+        self._g_obs_static = bool(getattr(buffer, "obs_static", False)) and os.environ.get("MACJD_LEARNER_STATIC_OBS", "1") != "0"
         self._g_idx = torch.zeros(self._g_B, dtype=torch.int64, device=self.device)
         self._g_idx_ring = [(torch.zeros(self._g_B, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(8)]
         if buffer.current_size < 1:
@@ -514,6 +528,7 @@ class QMixLearner:
             with torch.cuda.graph(self._graph_b, pool=self._graph_a.pool(), capture_error_mode="thread_local"):
                 self._g_out_b = self._clip_and_step()
         self._g_shared_body = self._body_is_shared()   # baked into the captured launches
+        assert self._g_obs_static == (bool(getattr(buffer, "obs_static", False)) and os.environ.get("MACJD_LEARNER_STATIC_OBS", "1") != "0")
         self._graphs_ready = True
 
     def train_from_buffer(self, indices=None, sync_stats=True, stats_row=None):
@@ -535,6 +550,9 @@ class QMixLearner:
         indices = np.asarray(indices, dtype=np.int64)
         if len(indices) != self._g_B or int(buf.episode_lengths[indices].min()) != self._g_T:
             return self._snap(self.train(buf.sample(len(indices), indices=indices), None, sync_stats=sync_stats), stats_row)
+        if self._g_obs_static and not buf.obs_static:
+            raise RuntimeError("an episode with unknown / changing observations was stored after enable_graphs() captured "
+                               "the static-observation update: call enable_graphs() again")
         if self._g_shared_body and not self._body_is_shared():
             raise RuntimeError("the agent body (fc1 / GRU / actor) of one controller changed after enable_graphs() captured "
                                "the shared-body update: call enable_graphs() again")

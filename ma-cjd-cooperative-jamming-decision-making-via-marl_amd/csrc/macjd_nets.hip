@@ -295,7 +295,10 @@ __global__ void __launch_bounds__(64 * NW) gru_sequence_kernel(const macjd_gru_i
         for (int g = 0; g < 3; ++g) bias[g][i] = bhh[g * H + u];
         h[i] = io.h0[net] ? io.h0[net][(int64_t)b * (io.h0_sb[net] ? io.h0_sb[net] : (int64_t)io.J * H) + (int64_t)j * H + u] : 0.0f;
     }
-    auto gi_row = [&](int t) { return gi + (((int64_t)b * T + t) * io.J + j) * (3 * H); };
+    // io.reserved != 0 ("gi_static"): gi is [B, 1, J, 3H], the same input transform at every step (static observation)
+    const bool gi_static = io.reserved != 0;
+    auto gi_row = [&](int t) { return gi_static ? gi + ((int64_t)b * io.J + j) * (3 * H)
+                                                : gi + (((int64_t)b * T + t) * io.J + j) * (3 * H); };
     if (T > 0) {
         const float* r0 = gi_row(0);
         const float* r1 = gi_row(T > 1 ? 1 : 0);

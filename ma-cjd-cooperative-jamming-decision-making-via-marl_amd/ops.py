@@ -285,14 +285,23 @@ def gru_sequence(gi: torch.Tensor, w_hh: torch.Tensor, b_hh: torch.Tensor,
     return gru_sequence_multi([gi], [w_hh], [b_hh], [h0])[0]
 
 
-def gru_sequence_multi(gis, w_hhs, b_hhs, h0s=None):
-    """Up to two networks (eval + target) scanned in ONE launch on a HIP device; host tensors loop."""
+def gru_sequence_multi(gis, w_hhs, b_hhs, h0s=None, n_steps=None):
+    """Up to two networks (eval + target) scanned in ONE launch on a HIP device; host tensors loop.  ``n_steps``: the
+    gi tensors are [B, 1, J, 3H] — one input transform per sequence, valid at every one of ``n_steps`` steps (static
+    observation) — instead of [B, T, J, 3H]."""
     n = len(gis)
     h0s = h0s if h0s is not None else [None] * n
+    static = n_steps is not None
+    if static:
+        assert all(g.shape[1] == 1 for g in gis)
     if not gis[0].is_cuda:
+        if static:
+            gis = [g.expand(-1, int(n_steps), -1, -1) for g in gis]
         return [gru_sequence_reference(g, w, b, h) for g, w, b, h in zip(gis, w_hhs, b_hhs, h0s)]
     lib = _native.load()
     B, T, J, H3 = gis[0].shape
+    if static:
+        T = int(n_steps)
     H = H3 // 3
     if H not in (64, 128):
         raise _native.NativeLibraryError(f"macjd_gru_sequence supports rnn_hidden_dim 64 or 128, got {H}")
@@ -302,6 +311,7 @@ def gru_sequence_multi(gis, w_hhs, b_hhs, h0s=None):
         keep = []
         cnt = min(2, n - start)
         io.n_nets, io.B, io.T, io.J, io.H = cnt, B, T, J, H
+        io.reserved = 1 if static else 0
         for k in range(cnt):
             g = gis[start + k].detach().float().contiguous()
             w = w_hhs[start + k].detach().float().contiguous()

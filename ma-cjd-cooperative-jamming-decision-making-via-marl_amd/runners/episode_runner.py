@@ -248,7 +248,13 @@ class BatchedEpisodeRunner:
         """Move the E finished episodes into the replay buffer (one transposing copy per key).  Row T of
         the T+1 arrays stays zero for full-length episodes, as in the reference."""
         if store and not test_mode:
-            self.buffer.store_episodes_batched(self.stage, self.batch_envs)
+            tags = None
+            if self._static:   # env e's static rows never change: identify them so that unchanged slots are not rewritten
+                if getattr(self, "_static_tags", None) is None:
+                    base = (id(self.env) & 0xFFFFFFFF) << 24
+                    self._static_tags = base + np.arange(self.batch_envs, dtype=np.int64)
+                tags = self._static_tags
+            self.buffer.store_episodes_batched(self.stage, self.batch_envs, obs_static=self._static, static_tags=tags)
 
     # ---- HIP-graph replay of a whole episode batch ----
     def enable_graph(self, n_steps=None):

@@ -60,6 +60,13 @@ class EpisodeReplayBuffer:
             "hidden_state": z((N, T + 1, J, args.rnn_hidden_dim), torch.float32),
         }
         self.episode_lengths = np.zeros(N, dtype=np.int64)  # host copy of sum(filled) per slot
+        # True while every stored episode came from an environment whose observation does not change within an episode
+        # (the batched runner says so when it stores; None = nothing stored yet).  The learner may then evaluate the
+        # observation-only parts of the agent once per sampled episode instead of once per step.
+        self.obs_static: Optional[bool] = None
+        # which static (state / obs / avail_actions) content each slot already holds: a caller-chosen integer per
+        # episode; a batched store skips re-copying those keys into slots that hold the very same content already
+        self._static_tag = np.full(N, -1, dtype=np.int64)
         self.current_index = 0
         self.current_size = 0
         self.lock = threading.Lock()
@@ -75,6 +82,8 @@ class EpisodeReplayBuffer:
             print("Warning: EpisodeReplayBuffer expects batch_size=1 from runner")
         with self.lock:
             idx = int(self._get_storage_idx(inc=batch_size)[0])
+            self.obs_static = False          # nothing is known about a single stored episode
+            self._static_tag[idx] = -1
             ep = {k: v[0] for k, v in episode_batch.items()}
             L = int(ep["reward"].shape[0])
             b = self.buffers
@@ -95,15 +104,20 @@ class EpisodeReplayBuffer:
             b["terminated"][idx, L:] = True  # padded steps count as terminated (replay_buffer.py:149)
             self.episode_lengths[idx] = L
 
-    def store_episodes_batched(self, stage: Dict[str, torch.Tensor], n_episodes: int, length: Optional[int] = None) -> None:
+    def store_episodes_batched(self, stage: Dict[str, torch.Tensor], n_episodes: int, length: Optional[int] = None,
+                               obs_static: bool = False, static_tags: Optional[np.ndarray] = None) -> None:
         """E full-length episodes at once from the batched runner's TIME-MAJOR staging tensors
         (``stage[key]`` is [T(+1), E, ...] on this device): one transposing copy per key into a
         contiguous slot range (split in two when the ring wraps).  ``length`` < episode_limit pads like
-        ``store_episode``."""
+        ``store_episode``.  ``obs_static``: these episodes' observations are constant in time (see ``self.obs_static``).
+        ``static_tags`` (int64 [E], >= 0): identity of each episode's state / obs / avail_actions content — slots that
+        already hold the same content (the same env's static rows, stored by an earlier rollout) are not rewritten,
+        which saves the larger half of the store's traffic (obs + state + mask: 393 of 720 MB at 3j/4r, E = 4096)."""
         T = self.episode_limit
         L = T if length is None else int(length)
         with self.lock:
             idx = self._get_storage_idx(inc=n_episodes)
+            self.obs_static = bool(obs_static) if self.obs_static is None else (self.obs_static and bool(obs_static))
             runs = []  # contiguous (slot_lo, slot_hi, src_lo) runs
             start = 0
             for i in range(1, len(idx) + 1):
@@ -113,10 +127,15 @@ class EpisodeReplayBuffer:
             b = self.buffers
             for lo, hi, s in runs:
                 n = hi - lo
+                tags = None if (static_tags is None or L < T) else np.asarray(static_tags[s:s + n], dtype=np.int64)
+                same_static = tags is not None and bool((tags >= 0).all()) and bool((self._static_tag[lo:hi] == tags).all())
                 for k in _T_PLUS_1:
+                    if same_static and k != "hidden_state":
+                        continue        # these slots already hold exactly this content
                     b[k][lo:hi, :L + 1].copy_(stage[k][:L + 1, s:s + n].transpose(0, 1))
                     if L < T:
                         b[k][lo:hi, L + 1:] = 0
+                self._static_tag[lo:hi] = tags if tags is not None else -1
                 for k in ("actions_discrete", "actions_continuous", "reward", "terminated"):
                     b[k][lo:hi, :L].copy_(stage[k][:L, s:s + n].transpose(0, 1))
                 b["filled"][lo:hi, :L] = True

@@ -624,6 +624,65 @@ def test_graphed_train_equals_eager_train(T, N, B, steps, single, shared, monkey
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-5, rtol=0, err_msg=k)
 
 
+def test_learner_static_observation_hoist_equals_per_step_evaluation(monkeypatch):
+    """Episodes stored by the batched runner carry ``buffer.obs_static``: the graphed update then evaluates the input
+    transform and the actor chain on the B * J step-0 rows only (the scan reads one input transform per sequence) instead
+    of on all B * (T + 1) * J identical rows.  Same kernels on the same row values: statistics and weights after several
+    updates equal the per-step evaluation (MACJD_LEARNER_STATIC_OBS=0); a single stored episode of unknown provenance
+    switches the buffer's flag off and the captured update refuses to replay."""
+    from macjd_amd.core.mac import BasicMAC
+    from macjd_amd.core.qmix import QMixLearner
+    from macjd_amd.runners.episode_runner import BatchedEpisodeRunner
+    from macjd_amd.simulation.environment import BatchedElectromagneticEnvironment
+    from macjd_amd.utils.replay_buffer import EpisodeReplayBuffer
+    sc, _ = load_scenario("3j4r")
+    E, Bsz = 64, 32
+    def build(hoist):
+        monkeypatch.setenv("MACJD_LEARNER_STATIC_OBS", "1" if hoist else "0")
+        env = BatchedElectromagneticEnvironment(scenario=sc, batch_envs=E, device=DEV, seed=5)
+        info = env.get_env_info()
+        d = dict(J=info["n_agents"], A=info["n_actions"], S=info["state_shape"], H=64)
+        args = _gpu_args(d, episode_limit=info["episode_limit"], buffer_size=2 * E, batch_size=Bsz, lr=1e-3, epsilon_start=0.5,
+                         target_update_interval=2)
+        args.env_info = info
+        torch.manual_seed(3)
+        with quiet():
+            mac = BasicMAC(info["obs_shape"], args)
+            buf = EpisodeReplayBuffer(args)
+            learner = QMixLearner(mac, args)
+        runner = BatchedEpisodeRunner(env, mac, buf, args)
+        runner.run(sync_stats=False)
+        assert buf.obs_static is True
+        learner.enable_graphs(buf, Bsz)
+        assert learner._g_obs_static == hoist
+        return learner, buf, mac, runner
+    la, ba, ma, ra = build(True)
+    lb, bb, mb, _ = build(False)
+    for k in ba.buffers:
+        assert torch.equal(ba.buffers[k], bb.buffers[k]), k
+    rng = np.random.default_rng(0)
+    for step in range(4):
+        idx = rng.choice(E, Bsz, replace=False)
+        sa, sb = la.train_from_buffer(indices=idx), lb.train_from_buffer(indices=idx)
+        for k in sa:
+            assert sa[k] == pytest.approx(sb[k], rel=1e-5, abs=1e-7), (step, k)
+    for (k, a), b in zip(ma.agent.state_dict().items(), mb.agent.state_dict().values()):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-6, rtol=0, err_msg=k)
+    for (k, a), b in zip(la.eval_qmix_net.state_dict().items(), lb.eval_qmix_net.state_dict().values()):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-6, rtol=0, err_msg=k)
+    # the second rollout re-stores the same envs' static rows: those slots are recognised and not rewritten, a different
+    # slot range is filled normally
+    ra.run(sync_stats=False)
+    assert ba.current_size == 2 * E and torch.equal(ba.buffers["obs"][:E], ba.buffers["obs"][E:])
+    # an episode of unknown provenance: flag off, the captured static-observation update refuses to run
+    ep = {k: [v[0].cpu().numpy()] for k, v in ba.buffers.items() if k != "filled"}
+    with quiet():
+        ba.store_episode(ep)
+    assert ba.obs_static is False
+    with pytest.raises(RuntimeError, match="enable_graphs"):
+        la.train_from_buffer()
+
+
 def test_shared_agent_body_equals_two_controller_unroll(monkeypatch):
     """Reference-faithful training never changes fc1 / GRU / actor (qmix.py:161-184), and the target controller is a
     copy (qmix.py:53): the learner evaluates that body ONCE for both networks.  Bitwise equal to the two-controller
