@@ -86,6 +86,14 @@ typedef struct macjd_gru_io {
     float* h_out[2];       /* [B,T,J,H] */
     int64_t h0_sb[2];      /* element stride between batch entries of h0 (0 = J*H, contiguous): lets the caller pass
                               step 0 of a stored [B,T+1,J,H] hidden-state tensor without copying it */
+    /* Static observation, input transform computed IN the kernel (gi[] may then be NULL): sequence (b, j) reads its
+       observation row obs + row(b) * obs_sb + j * obs_sj (row(b) = obs_index[b] if obs_index else b — e.g. the sampled
+       episodes' step-0 rows straight out of the replay ring, no gather in front of the scan) and evaluates
+       gi = W_ih ReLU(fc1 obs + b_fc1) + b_ih once (reference core/networks.py:96-100), used at every step. */
+    const float* obs;      int64_t obs_sb, obs_sj;   int32_t S, reserved2;
+    const int64_t* obs_index;                        /* optional [B] */
+    const float* fc1_w[2]; const float* fc1_b[2];    /* fc1.weight [H,S], fc1.bias [H] */
+    const float* w_ih[2];  const float* b_ih[2];     /* rnn.weight_ih [3H,H], rnn.bias_ih [3H] */
 } macjd_gru_io;
 
 int macjd_gru_sequence(const macjd_gru_io* io, void* hip_stream);

@@ -87,6 +87,9 @@ class GruIO(ctypes.Structure):
         ("H", ctypes.c_int32), ("reserved", ctypes.c_int32),
         ("gi", ctypes.c_void_p * 2), ("w_hh", ctypes.c_void_p * 2), ("b_hh", ctypes.c_void_p * 2),
         ("h0", ctypes.c_void_p * 2), ("h_out", ctypes.c_void_p * 2), ("h0_sb", ctypes.c_int64 * 2),
+        ("obs", ctypes.c_void_p), ("obs_sb", ctypes.c_int64), ("obs_sj", ctypes.c_int64), ("S", ctypes.c_int32), ("reserved2", ctypes.c_int32),
+        ("obs_index", ctypes.c_void_p),
+        ("fc1_w", ctypes.c_void_p * 2), ("fc1_b", ctypes.c_void_p * 2), ("w_ih", ctypes.c_void_p * 2), ("b_ih", ctypes.c_void_p * 2),
     ]
 
 

@@ -279,7 +279,24 @@ class QMixLearner:
             self._flatten_grads()   # one cat: the all-reduce buffer and the fused optimiser's input
         return loss.detach(), eval_mean.detach(), target_mean.detach()
 
-    def _forward_backward_full(self, st, T):
+    def _scan_from_ring_early(self):
+        """Static observations: launch the scan (with its in-kernel input transform) on the side stream BEFORE the
+        gather — it reads the sampled episodes' step-0 observation rows straight from the replay ring through the index
+        tensor, so the longest kernel of the update starts at time zero.  Returns the per-agent hidden states (side stream)."""
+        dev = self.device
+        origin = torch.cuda.current_stream(dev)
+        if getattr(self, "_target_stream", None) is None:
+            self._target_stream = torch.cuda.Stream(device=dev)
+        ts = self._target_stream
+        ts.wait_stream(origin)                                                                  # fork
+        shared = self._body_is_shared()
+        agents = [self.mac.agent] if shared else [self.target_mac.agent, self.mac.agent]
+        with torch.cuda.stream(ts), torch.no_grad():
+            h = ops.gru_sequence_from_obs(self._g_buffer.buffers["obs"], self._g_idx, agents, self._g_B, self.n_agents,
+                                          self._g_T + 1)
+        return [h[0], h[0]] if shared else h
+
+    def _forward_backward_full(self, st, T, pre_scan=None):
         """Same update as ``_forward_backward`` for a batch of FULL-LENGTH episodes held in contiguous staging
         tensors with T+1 steps on every key (actions padded with a zero row).  Every quantity is evaluated for
         all T+1 steps and the loss kernel picks the steps it needs through strides, so no slice of a [B,T+1,...]
@@ -322,7 +339,16 @@ class QMixLearner:
         # every fork hangs off the capture's origin stream.  MACJD_UPDATE_STREAMS=1 runs everything on one stream.
         def scan_chain():
             ns = T1 if obs_static else None
-            if shared:
+            if pre_scan is not None:
+                h_alls = pre_scan        # already running on the side stream (_scan_from_ring_early)
+            elif obs_static and rows.is_cuda and getattr(self, "_g_scan_from_ring", False):
+                # the scan launch computes each sequence's input transform itself, from the sampled episodes' step-0
+                # observation rows in the replay ring: no fc1 / W_ih launch
+                ring = self._g_buffer.buffers["obs"]
+                h_alls = ops.gru_sequence_from_obs(ring, self._g_idx, [body] if shared else [m.agent for m in macs], B, J, T1)
+                if shared:
+                    h_alls = [h_alls[0], h_alls[0]]
+            elif shared:
                 gis = [body.gru_input_transform(rows_s).view(B, Tg, J, 3 * H)]                 # networks.py:100
                 h = ops.gru_sequence_multi(gis, [body.rnn.weight_hh], [body.rnn.bias_hh], n_steps=ns)[0]   # h_0 = 0, qmix.py:241
                 h_alls = [h, h]
@@ -459,6 +485,8 @@ class QMixLearner:
         self._g_buffer, self._g_B, self._g_T = buffer, int(batch_size), int(buffer.episode_limit)
         # static observations in every stored episode (see _forward_backward_full): baked into the captured launches
         self._g_obs_static = bool(getattr(buffer, "obs_static", False)) and os.environ.get("MACJD_LEARNER_STATIC_OBS", "1") != "0"
+        self._g_scan_from_ring = self._g_obs_static and os.environ.get("MACJD_SCAN_FROM_RING", "1") != "0" \
+            and int(buffer.buffers["obs"].shape[-1]) <= 3 * int(self.args.rnn_hidden_dim)
         self._g_idx = torch.zeros(self._g_B, dtype=torch.int64, device=self.device)
         self._g_idx_ring = [(torch.zeros(self._g_B, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(8)]
         if buffer.current_size < 1:
@@ -477,8 +505,11 @@ class QMixLearner:
 
         def body_a():
             if fused:
+                pre = None
+                if self._g_scan_from_ring and os.environ.get("MACJD_UPDATE_STREAMS", "2") != "1":
+                    pre = self._scan_from_ring_early()
                 ops.gather_rows(self._g_idx, srcs, [stage[k] for k in keys])
-                return self._forward_backward_full(stage, self._g_T)
+                return self._forward_backward_full(stage, self._g_T, pre_scan=pre)
             b = {k: v.index_select(0, self._g_idx) for k, v in zip(keys, srcs)}
             return self._forward_backward(b, self._g_T, validate_actions=False)
 

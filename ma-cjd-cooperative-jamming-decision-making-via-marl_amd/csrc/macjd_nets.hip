@@ -269,6 +269,7 @@ __global__ void __launch_bounds__(64 * NW) gru_sequence_kernel(const macjd_gru_i
     float* __restrict__ out = io.h_out[net];
 
     __shared__ float s_part[2][NW][3][H];
+    __shared__ float s_gi[3 * H];   // in-kernel input transform (static observation), see macjd_gru_io.obs
 
     // weights of this wave's K-slice, resident for the whole sequence
     float w[3][U][KW];
@@ -296,9 +297,39 @@ __global__ void __launch_bounds__(64 * NW) gru_sequence_kernel(const macjd_gru_i
         h[i] = io.h0[net] ? io.h0[net][(int64_t)b * (io.h0_sb[net] ? io.h0_sb[net] : (int64_t)io.J * H) + (int64_t)j * H + u] : 0.0f;
     }
     // io.reserved != 0 ("gi_static"): gi is [B, 1, J, 3H], the same input transform at every step (static observation)
-    const bool gi_static = io.reserved != 0;
-    auto gi_row = [&](int t) { return gi_static ? gi + ((int64_t)b * io.J + j) * (3 * H)
-                                                : gi + (((int64_t)b * T + t) * io.J + j) * (3 * H); };
+    const bool gi_inkernel = io.obs != nullptr;
+    const bool gi_static = io.reserved != 0 || gi_inkernel;
+    if (gi_inkernel) {
+        // gi = W_ih ReLU(fc1 x + b_fc1) + b_ih for this sequence's ONE observation row: two small mat-vecs on the VALU
+        // (S x H + H x 3H multiply-adds, the weights come from L2), shared through LDS.  s_part doubles as scratch.
+        float* xs = &s_part[0][0][0][0];        // [S] (S <= 3 H NW floats available)
+        float* h1 = &s_part[1][0][0][0];        // [H]
+        const int64_t row = io.obs_index ? io.obs_index[b] : (int64_t)b;
+        const float* x = io.obs + row * io.obs_sb + (int64_t)j * io.obs_sj;
+        const int S = io.S;
+        for (int k = threadIdx.x; k < S; k += 64 * NW) xs[k] = x[k];
+        __syncthreads();
+        for (int o = threadIdx.x; o < H; o += 64 * NW) {
+            const float* wr = io.fc1_w[net] + (int64_t)o * S;
+            float a = io.fc1_b[net][o];
+            for (int k = 0; k < S; ++k) a = fmaf(wr[k], xs[k], a);
+            h1[o] = fmaxf(a, 0.0f);
+        }
+        __syncthreads();
+        for (int o = threadIdx.x; o < 3 * H; o += 64 * NW) {
+            const float* wr = io.w_ih[net] + (int64_t)o * H;
+            float a = io.b_ih[net][o];
+#pragma unroll 8
+            for (int k = 0; k < H; ++k) a = fmaf(wr[k], h1[k], a);
+            s_gi[o] = a;
+        }
+        __syncthreads();
+    }
+    auto gi_row = [&](int t) -> const float* {
+        return gi_inkernel ? (const float*)s_gi
+                           : gi_static ? gi + ((int64_t)b * io.J + j) * (3 * H)
+                                       : gi + (((int64_t)b * T + t) * io.J + j) * (3 * H);
+    };
     if (T > 0) {
         const float* r0 = gi_row(0);
         const float* r1 = gi_row(T > 1 ? 1 : 0);
@@ -389,9 +420,14 @@ extern "C" int macjd_gru_sequence(const macjd_gru_io* io, void* hip_stream) {
     if (io->n_nets < 1 || io->n_nets > 2 || io->B < 0 || io->T < 0 || io->J < 1)
         return set_nets_err(MACJD_EINVAL, "macjd_gru_sequence: bad n_nets / B / T / J");
     if (io->H != 64 && io->H != 128) return set_nets_err(MACJD_EUNSUPPORTED, "macjd_gru_sequence: H must be 64 or 128");
-    for (int n = 0; n < io->n_nets; ++n)
-        if (!io->gi[n] || !io->w_hh[n] || !io->b_hh[n] || !io->h_out[n])
+    for (int n = 0; n < io->n_nets; ++n) {
+        if ((!io->gi[n] && !io->obs) || !io->w_hh[n] || !io->b_hh[n] || !io->h_out[n])
             return set_nets_err(MACJD_EINVAL, "macjd_gru_sequence: NULL pointer");
+        if (io->obs && (!io->fc1_w[n] || !io->fc1_b[n] || !io->w_ih[n] || !io->b_ih[n]))
+            return set_nets_err(MACJD_EINVAL, "macjd_gru_sequence: in-kernel input transform needs fc1 / W_ih");
+    }
+    if (io->obs && (io->S < 1 || io->S > 3 * io->H))
+        return set_nets_err(MACJD_EINVAL, "macjd_gru_sequence: in-kernel input transform needs 1 <= S <= 3H");
     if (io->B == 0 || io->T == 0) return MACJD_OK;
     const dim3 g((unsigned)(io->B * io->J), (unsigned)io->n_nets);
     hipStream_t s = (hipStream_t)hip_stream;

@@ -285,6 +285,40 @@ def gru_sequence(gi: torch.Tensor, w_hh: torch.Tensor, b_hh: torch.Tensor,
     return gru_sequence_multi([gi], [w_hh], [b_hh], [h0])[0]
 
 
+def gru_sequence_from_obs(obs, obs_index, agents, B: int, J: int, n_steps: int):
+    """Scan of up to two agents whose observation is static within an episode, with the input transform computed INSIDE
+    the scan launch: sequence (b, j) reads the observation row ``obs[obs_index[b], 0, j]`` (``obs`` [N, T+1, J, S]: the
+    replay ring itself; ``obs_index`` int64 [B] on the device, or None for rows 0..B-1) and evaluates
+    gi = W_ih ReLU(fc1 x + b) + b_ih once (reference core/networks.py:96-100).  No separate fc1 / W_ih launch and no
+    dependence on a gather in front of the scan.  Returns [h_all [B, n_steps, J, H]] per agent (HIP device only)."""
+    lib = _native.load()
+    assert obs.is_cuda and obs.dtype == torch.float32 and obs.dim() == 4 and obs.stride(3) == 1 and obs.shape[2] == J
+    outs = []
+    for start in range(0, len(agents), 2):
+        part = agents[start:start + 2]
+        H = part[0].rnn_hidden_dim
+        if H not in (64, 128):
+            raise _native.NativeLibraryError(f"macjd_gru_sequence supports rnn_hidden_dim 64 or 128, got {H}")
+        io = _native.GruIO()
+        io.n_nets, io.B, io.T, io.J, io.H = len(part), int(B), int(n_steps), int(J), H
+        io.obs, io.obs_sb, io.obs_sj, io.S = obs.data_ptr(), obs.stride(0), obs.stride(2), obs.shape[3]
+        if obs_index is not None:
+            assert obs_index.dtype == torch.int64 and obs_index.is_cuda and obs_index.numel() >= B
+            io.obs_index = obs_index.data_ptr()
+        keep = []
+        for k, a in enumerate(part):
+            ts = [t.detach().float().contiguous() for t in (a.rnn.weight_hh, a.rnn.bias_hh, a.fc1.weight, a.fc1.bias,
+                                                            a.rnn.weight_ih, a.rnn.bias_ih)]
+            keep += ts
+            io.w_hh[k], io.b_hh[k], io.fc1_w[k], io.fc1_b[k], io.w_ih[k], io.b_ih[k] = [t.data_ptr() for t in ts]
+            o = torch.empty((B, n_steps, J, H), dtype=torch.float32, device=obs.device)
+            io.h_out[k] = o.data_ptr()
+            outs.append(o)
+        with torch.cuda.device(obs.device):
+            _native.check(lib.macjd_gru_sequence(ctypes.byref(io), _stream(obs)), "macjd_gru_sequence")
+    return outs
+
+
 def gru_sequence_multi(gis, w_hhs, b_hhs, h0s=None, n_steps=None):
     """Up to two networks (eval + target) scanned in ONE launch on a HIP device; host tensors loop.  ``n_steps``: the
     gi tensors are [B, 1, J, 3H] — one input transform per sequence, valid at every one of ``n_steps`` steps (static
