@@ -94,6 +94,12 @@ typedef struct macjd_gru_io {
     const int64_t* obs_index;                        /* optional [B] */
     const float* fc1_w[2]; const float* fc1_b[2];    /* fc1.weight [H,S], fc1.bias [H] */
     const float* w_ih[2];  const float* b_ih[2];     /* rnn.weight_ih [3H,H], rnn.bias_ih [3H] */
+    /* optional, with obs: the frozen actor chain of the same observation row (core/networks.py:116-129),
+       p_out[net][(b * J + j) * A + a] = sigmoid(L3 ReLU(L2 ReLU(L1 x))) — the continuous parameter of every action,
+       one row per SEQUENCE (it is the same at every step).  Ah <= 256, A <= 64. */
+    float* p_out[2];
+    const float* act_w[2][3]; const float* act_b[2][3];   /* actor.{0,2,4}.{weight,bias}: [Ah,S], [Ah,Ah], [A,Ah] */
+    int32_t Ah, A;
 } macjd_gru_io;
 
 int macjd_gru_sequence(const macjd_gru_io* io, void* hip_stream);
@@ -468,6 +474,9 @@ typedef struct macjd_doubleq_io {
     const float* W1_t; int64_t w1t_ld; const float* b1_t; const float* w2_t; const float* b2_t;   /* target fc2_q_head */
     float* out;              /* [n] */
     int64_t* argmax_out;     /* optional [n] */
+    /* optional row map of P_e / P_t: p_group > 0 -> row n reads P row (n / p_group) * p_inner + n % p_inner (one actor
+       row per SEQUENCE (b, j) for rows n = (b, t, j): p_group = T * J, p_inner = J) */
+    int64_t p_group, p_inner;
 } macjd_doubleq_io;
 
 int macjd_qhead_double_q_supported(int32_t H, int32_t A);

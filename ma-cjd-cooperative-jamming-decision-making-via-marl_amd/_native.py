@@ -90,6 +90,8 @@ class GruIO(ctypes.Structure):
         ("obs", ctypes.c_void_p), ("obs_sb", ctypes.c_int64), ("obs_sj", ctypes.c_int64), ("S", ctypes.c_int32), ("reserved2", ctypes.c_int32),
         ("obs_index", ctypes.c_void_p),
         ("fc1_w", ctypes.c_void_p * 2), ("fc1_b", ctypes.c_void_p * 2), ("w_ih", ctypes.c_void_p * 2), ("b_ih", ctypes.c_void_p * 2),
+        ("p_out", ctypes.c_void_p * 2), ("act_w", (ctypes.c_void_p * 3) * 2), ("act_b", (ctypes.c_void_p * 3) * 2),
+        ("Ah", ctypes.c_int32), ("A", ctypes.c_int32),
     ]
 
 
@@ -143,7 +145,7 @@ class DoubleQIO(ctypes.Structure):
         ("P_e", ctypes.c_void_p), ("pe_ld", ctypes.c_int64), ("P_t", ctypes.c_void_p), ("pt_ld", ctypes.c_int64),
         ("W1_e", ctypes.c_void_p), ("w1e_ld", ctypes.c_int64), ("b1_e", ctypes.c_void_p), ("w2_e", ctypes.c_void_p), ("b2_e", ctypes.c_void_p),
         ("W1_t", ctypes.c_void_p), ("w1t_ld", ctypes.c_int64), ("b1_t", ctypes.c_void_p), ("w2_t", ctypes.c_void_p), ("b2_t", ctypes.c_void_p),
-        ("out", ctypes.c_void_p), ("argmax_out", ctypes.c_void_p),
+        ("out", ctypes.c_void_p), ("argmax_out", ctypes.c_void_p), ("p_group", ctypes.c_int64), ("p_inner", ctypes.c_int64),
     ]
 
 

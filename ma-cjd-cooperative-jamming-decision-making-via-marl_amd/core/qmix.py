@@ -292,11 +292,14 @@ class QMixLearner:
         shared = self._body_is_shared()
         agents = [self.mac.agent] if shared else [self.target_mac.agent, self.mac.agent]
         with torch.cuda.stream(ts), torch.no_grad():
-            h = ops.gru_sequence_from_obs(self._g_buffer.buffers["obs"], self._g_idx, agents, self._g_B, self.n_agents,
-                                          self._g_T + 1)
-        return [h[0], h[0]] if shared else h
+            # (the frozen actor chain of each sequence's observation row rides in the scan launch's prologue as well: a
+            # separate 96-row actor launch costs ~20 us of pure latency, a third stream for it ~30 us of graph-branch
+            # start-up — measured 0.216 -> 0.246 ms / step)
+            h, ps = ops.gru_sequence_from_obs(self._g_buffer.buffers["obs"], self._g_idx, agents, self._g_B, self.n_agents,
+                                              self._g_T + 1, with_actor=True)
+        return ([h[0], h[0]] if shared else h), ([ps[0], ps[0]] if shared else ps)
 
-    def _forward_backward_full(self, st, T, pre_scan=None):
+    def _forward_backward_full(self, st, T, pre_scan=None, pre_actor=None):
         """Same update as ``_forward_backward`` for a batch of FULL-LENGTH episodes held in contiguous staging
         tensors with T+1 steps on every key (actions padded with a zero row).  Every quantity is evaluated for
         all T+1 steps and the loss kernel picks the steps it needs through strides, so no slice of a [B,T+1,...]
@@ -371,7 +374,10 @@ class QMixLearner:
             # hidden states, or two Q-head launches on library-GEMM bases
             if fused_dq:
                 hd4 = [(hd[0], m.agent.fc2_q_head[0].bias, hd[1], hd[2]) for m, hd in zip(macs, heads)]
-                return ops.qhead_double_q_from_h(bases[1], params[1], hd4[1], bases[0], params[0], hd4[0], H, A).view(B, T1, J)
+                # P per sequence [B, J, A] (static observation): row n = (b, t, j) reads P[b, j]
+                pmap = (T1 * J, J) if (pre_actor is not None and params[1].shape[0] != n) else None
+                return ops.qhead_double_q_from_h(bases[1], params[1], hd4[1], bases[0], params[0], hd4[0], H, A,
+                                                 p_row_map=pmap).view(B, T1, J)
             return ops.qhead_double_q(bases[1], params[1], heads[1], bases[0], params[0], heads[0], H, A).view(B, T1, J)
 
         def eval_forward():
@@ -389,16 +395,22 @@ class QMixLearner:
             ts.wait_stream(origin)                                                              # fork
             with torch.cuda.stream(ts), torch.no_grad():
                 bases = scan_chain()
-                p_target = None if shared else actor_all(macs[0].agent)
-            with torch.no_grad():
-                p_eval = actor_all(body)
+                p_target = None if (shared or pre_actor is not None) else actor_all(macs[0].agent)
+            if pre_actor is not None:      # [B, J, A] per controller, from the scan launch's prologue: [target, eval]
+                p_target, p_eval = (None if shared else pre_actor[0]), pre_actor[1]
+                if not fused_dq:           # the two-launch Double-DQN form wants one row per (b, t, j)
+                    ex = lambda p_: p_.view(B, 1, J, A).expand(B, T1, J, A).reshape(n, A)
+                    p_target, p_eval = (None if p_target is None else ex(p_target)), ex(p_eval)
+            else:
+                with torch.no_grad():
+                    p_eval = actor_all(body)
             eval_q_tot = eval_forward()
             with torch.no_grad():
                 # unfused mixer: its state-only half (LayerNorm + hyper-networks) runs here, before the join; the fused
                 # mixer is ONE launch that needs the target Q-values, i.e. it runs behind the join
                 hyper = None if self.target_qmix_net.fused_available(st["state"]) else self.target_qmix_net.hyper_outputs(st["state"])
                 origin.wait_stream(ts)                                                          # join
-                for t_ in list(bases) + ([p_target] if p_target is not None else []):
+                for t_ in list(bases) + ([p_target] if p_target is not None else []) + ([p_eval] if pre_actor is not None else []):
                     t_.record_stream(origin)
                 params = [p_eval if shared else p_target, p_eval]
                 target_q_tot = self.target_qmix_net(double_q(bases, params), st["state"], hyper=hyper)   # qmix.py:151
@@ -505,11 +517,11 @@ class QMixLearner:
 
         def body_a():
             if fused:
-                pre = None
+                pre = (None, None)
                 if self._g_scan_from_ring and os.environ.get("MACJD_UPDATE_STREAMS", "2") != "1":
                     pre = self._scan_from_ring_early()
                 ops.gather_rows(self._g_idx, srcs, [stage[k] for k in keys])
-                return self._forward_backward_full(stage, self._g_T, pre_scan=pre)
+                return self._forward_backward_full(stage, self._g_T, pre_scan=pre[0], pre_actor=pre[1])
             b = {k: v.index_select(0, self._g_idx) for k, v in zip(keys, srcs)}
             return self._forward_backward(b, self._g_T, validate_actions=False)
 

@@ -292,7 +292,8 @@ __global__ void __launch_bounds__(256) qhead_double_q_kernel(const macjd_doubleq
     const int64_t nq = (n0 + qr < io.n_rows) ? n0 + qr : io.n_rows - 1;
     float pv[A];
     {
-        const float* prow = (wave == 1) ? io.P_t + nq * io.pt_ld : io.P_e + nq * io.pe_ld;
+        const int64_t np = io.p_group > 0 ? (nq / io.p_group) * io.p_inner + nq % io.p_inner : nq;   // one P row per sequence
+        const float* prow = (wave == 1) ? io.P_t + np * io.pt_ld : io.P_e + np * io.pe_ld;
 #pragma unroll
         for (int a = 0; a < A; ++a) pv[a] = prow[a];
     }

@@ -243,6 +243,12 @@ extern "C" int macjd_qhead_select(const macjd_qhead_io* io, void* hip_stream) {
 //   * gi for step t+1 is loaded while step t computes; wave 0 stores h' (256-B coalesced rows).
 namespace macjd {
 
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+
 // v_rcp_f32 / v_exp_f32 directly (1 ulp each): __frcp_rn is the CORRECTLY ROUNDED reciprocal and expands to the full
 // div_scale / div_fmas / div_fixup sequence, ~12 instructions per gate on the serial per-step chain
 __device__ __forceinline__ float gru_sigmoid(float x) {
@@ -270,6 +276,7 @@ __global__ void __launch_bounds__(64 * NW) gru_sequence_kernel(const macjd_gru_i
 
     __shared__ float s_part[2][NW][3][H];
     __shared__ float s_gi[3 * H];   // in-kernel input transform (static observation), see macjd_gru_io.obs
+    __shared__ float s_pro[768];    // prologue scratch: observation row + two hidden vectors
 
     // weights of this wave's K-slice, resident for the whole sequence
     float w[3][U][KW];
@@ -300,28 +307,40 @@ __global__ void __launch_bounds__(64 * NW) gru_sequence_kernel(const macjd_gru_i
     const bool gi_inkernel = io.obs != nullptr;
     const bool gi_static = io.reserved != 0 || gi_inkernel;
     if (gi_inkernel) {
-        // gi = W_ih ReLU(fc1 x + b_fc1) + b_ih for this sequence's ONE observation row: two small mat-vecs on the VALU
-        // (S x H + H x 3H multiply-adds, the weights come from L2), shared through LDS.  s_part doubles as scratch.
-        float* xs = &s_part[0][0][0][0];        // [S] (S <= 3 H NW floats available)
-        float* h1 = &s_part[1][0][0][0];        // [H]
+        // Prologue for a static observation: this sequence's ONE observation row x -> gi = W_ih ReLU(fc1 x + b) + b_ih
+        // and, when asked, the actor chain sigmoid(L3 ReLU(L2 ReLU(L1 x))).  Small mat-vecs on the VALU: an output is a
+        // wave-wide dot product (lanes split k: every weight row is read as coalesced 256-B pieces from L2), outputs are
+        // dealt round-robin to the NW waves; layers meet in LDS.
+        float* xs = s_pro;              // [S]
+        float* v1 = s_pro + 256;        // [<= 256] first hidden vector
+        float* v2 = s_pro + 512;        // [<= 256] second hidden vector
         const int64_t row = io.obs_index ? io.obs_index[b] : (int64_t)b;
         const float* x = io.obs + row * io.obs_sb + (int64_t)j * io.obs_sj;
         const int S = io.S;
         for (int k = threadIdx.x; k < S; k += 64 * NW) xs[k] = x[k];
         __syncthreads();
-        for (int o = threadIdx.x; o < H; o += 64 * NW) {
-            const float* wr = io.fc1_w[net] + (int64_t)o * S;
-            float a = io.fc1_b[net][o];
-            for (int k = 0; k < S; ++k) a = fmaf(wr[k], xs[k], a);
-            h1[o] = fmaxf(a, 0.0f);
-        }
+        auto matvec = [&](const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ vin, int K,
+                          int N, auto&& store) {   // store(o, value) for o in [0, N), one wave per output
+            for (int o = wave; o < N; o += NW) {
+                const float* wr = W + (int64_t)o * K;
+                float a = 0.0f;
+                for (int k = lane; k < K; k += 64) a = fmaf(wr[k], vin[k], a);
+                a = wave_sum(a);
+                if (lane == 0) store(o, a + bias[o]);
+            }
+        };
+        matvec(io.fc1_w[net], io.fc1_b[net], xs, S, H, [&](int o, float v) { v1[o] = fmaxf(v, 0.0f); });
         __syncthreads();
-        for (int o = threadIdx.x; o < 3 * H; o += 64 * NW) {
-            const float* wr = io.w_ih[net] + (int64_t)o * H;
-            float a = io.b_ih[net][o];
-#pragma unroll 8
-            for (int k = 0; k < H; ++k) a = fmaf(wr[k], h1[k], a);
-            s_gi[o] = a;
+        matvec(io.w_ih[net], io.b_ih[net], v1, H, 3 * H, [&](int o, float v) { s_gi[o] = v; });
+        if (io.p_out[net]) {
+            const int Ah = io.Ah, A = io.A;
+            __syncthreads();    // v1 is read by the W_ih product above: done before it is overwritten
+            matvec(io.act_w[net][0], io.act_b[net][0], xs, S, Ah, [&](int o, float v) { v1[o] = fmaxf(v, 0.0f); });
+            __syncthreads();
+            matvec(io.act_w[net][1], io.act_b[net][1], v1, Ah, Ah, [&](int o, float v) { v2[o] = fmaxf(v, 0.0f); });
+            __syncthreads();
+            float* po = io.p_out[net] + ((int64_t)b * io.J + j) * A;
+            matvec(io.act_w[net][2], io.act_b[net][2], v2, Ah, A, [&](int o, float v) { po[o] = 1.0f / (1.0f + expf(-v)); });
         }
         __syncthreads();
     }
@@ -426,8 +445,16 @@ extern "C" int macjd_gru_sequence(const macjd_gru_io* io, void* hip_stream) {
         if (io->obs && (!io->fc1_w[n] || !io->fc1_b[n] || !io->w_ih[n] || !io->b_ih[n]))
             return set_nets_err(MACJD_EINVAL, "macjd_gru_sequence: in-kernel input transform needs fc1 / W_ih");
     }
-    if (io->obs && (io->S < 1 || io->S > 3 * io->H))
-        return set_nets_err(MACJD_EINVAL, "macjd_gru_sequence: in-kernel input transform needs 1 <= S <= 3H");
+    if (io->obs && (io->S < 1 || io->S > 256))
+        return set_nets_err(MACJD_EINVAL, "macjd_gru_sequence: in-kernel input transform needs 1 <= S <= 256");
+    for (int n = 0; n < io->n_nets; ++n)
+        if (io->obs && io->p_out[n]) {
+            if (io->Ah < 1 || io->Ah > 256 || io->A < 1 || io->A > 64)
+                return set_nets_err(MACJD_EINVAL, "macjd_gru_sequence: in-kernel actor needs Ah <= 256, A <= 64");
+            for (int l = 0; l < 3; ++l)
+                if (!io->act_w[n][l] || !io->act_b[n][l])
+                    return set_nets_err(MACJD_EINVAL, "macjd_gru_sequence: in-kernel actor needs its three layers");
+        }
     if (io->B == 0 || io->T == 0) return MACJD_OK;
     const dim3 g((unsigned)(io->B * io->J), (unsigned)io->n_nets);
     hipStream_t s = (hipStream_t)hip_stream;
@@ -447,11 +474,6 @@ extern "C" int macjd_gru_sequence(const macjd_gru_io* io, void* hip_stream) {
 // per mixer call of the unfused form.
 namespace macjd {
 
-__device__ __forceinline__ float wave_sum(float x) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
-    return x;
-}
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
 template <bool BACKWARD>

@@ -95,7 +95,8 @@ def qhead_double_q_fused_supported(h, H: int, A: int) -> bool:
     return h.is_cuda and bool(_native.load().macjd_qhead_double_q_supported(int(H), int(A)))
 
 
-def qhead_double_q_from_h(h_eval, P_eval, head_eval, h_tgt, P_tgt, head_tgt, H: int, A: int, want_argmax: bool = False):
+def qhead_double_q_from_h(h_eval, P_eval, head_eval, h_tgt, P_tgt, head_tgt, H: int, A: int, want_argmax: bool = False,
+                          p_row_map=None):
     """Double-DQN target values [N] straight from the unrolled hidden states, ONE launch (csrc/macjd_episode.hip,
     qhead_double_q_kernel): both Q-head base products on the matrix cores, both all-action Q-heads, unmasked arg-max of
     the eval head, gather from the target head (reference core/qmix.py:138-147).  ``head_* = (W1 [H, H+A+1], b1 [H],
@@ -114,7 +115,11 @@ def qhead_double_q_from_h(h_eval, P_eval, head_eval, h_tgt, P_tgt, head_tgt, H: 
     io = _native.DoubleQIO()
     io.n_rows, io.H, io.A = N, H, A
     io.h_e, io.he_ld, io.h_t, io.ht_ld = h_e.data_ptr(), h_e.stride(0), h_t.data_ptr(), h_t.stride(0)
+    if P_e.dim() != 2:
+        P_e, P_t = P_e.reshape(-1, A), P_t.reshape(-1, A)
     io.P_e, io.pe_ld, io.P_t, io.pt_ld = P_e.data_ptr(), P_e.stride(0), P_t.data_ptr(), P_t.stride(0)
+    if p_row_map is not None:    # (rows per group, P rows per group): row n reads P row (n // group) * inner + n % inner
+        io.p_group, io.p_inner = int(p_row_map[0]), int(p_row_map[1])
     for tag, head in (("e", head_eval), ("t", head_tgt)):
         W1, b1 = c(head[0]), c(head[1]).contiguous()
         w2, b2 = c(head[2]).reshape(-1).contiguous(), c(head[3]).reshape(-1).contiguous()
@@ -285,15 +290,16 @@ def gru_sequence(gi: torch.Tensor, w_hh: torch.Tensor, b_hh: torch.Tensor,
     return gru_sequence_multi([gi], [w_hh], [b_hh], [h0])[0]
 
 
-def gru_sequence_from_obs(obs, obs_index, agents, B: int, J: int, n_steps: int):
+def gru_sequence_from_obs(obs, obs_index, agents, B: int, J: int, n_steps: int, with_actor: bool = False):
     """Scan of up to two agents whose observation is static within an episode, with the input transform computed INSIDE
     the scan launch: sequence (b, j) reads the observation row ``obs[obs_index[b], 0, j]`` (``obs`` [N, T+1, J, S]: the
     replay ring itself; ``obs_index`` int64 [B] on the device, or None for rows 0..B-1) and evaluates
     gi = W_ih ReLU(fc1 x + b) + b_ih once (reference core/networks.py:96-100).  No separate fc1 / W_ih launch and no
-    dependence on a gather in front of the scan.  Returns [h_all [B, n_steps, J, H]] per agent (HIP device only)."""
+    dependence on a gather in front of the scan.  Returns [h_all [B, n_steps, J, H]] per agent (HIP device only);
+    ``with_actor``: also the actor output of every sequence's observation row, ([h_all ...], [P [B, J, A] ...])."""
     lib = _native.load()
     assert obs.is_cuda and obs.dtype == torch.float32 and obs.dim() == 4 and obs.stride(3) == 1 and obs.shape[2] == J
-    outs = []
+    outs, pouts = [], []
     for start in range(0, len(agents), 2):
         part = agents[start:start + 2]
         H = part[0].rnn_hidden_dim
@@ -314,9 +320,18 @@ def gru_sequence_from_obs(obs, obs_index, agents, B: int, J: int, n_steps: int):
             o = torch.empty((B, n_steps, J, H), dtype=torch.float32, device=obs.device)
             io.h_out[k] = o.data_ptr()
             outs.append(o)
+            if with_actor:
+                layers = [(w.detach().float().contiguous(), b_.detach().float().contiguous()) for w, b_, _ in a.actor_layers()]
+                keep += [t for pair in layers for t in pair]
+                for l, (w, b_) in enumerate(layers):
+                    io.act_w[k][l], io.act_b[k][l] = w.data_ptr(), b_.data_ptr()
+                io.Ah, io.A = layers[0][0].shape[0], layers[2][0].shape[0]
+                pk_ = torch.empty((B, J, io.A), dtype=torch.float32, device=obs.device)
+                io.p_out[k] = pk_.data_ptr()
+                pouts.append(pk_)
         with torch.cuda.device(obs.device):
             _native.check(lib.macjd_gru_sequence(ctypes.byref(io), _stream(obs)), "macjd_gru_sequence")
-    return outs
+    return (outs, pouts) if with_actor else outs
 
 
 def gru_sequence_multi(gis, w_hhs, b_hhs, h0s=None, n_steps=None):

@@ -915,6 +915,42 @@ def test_gru_gates_kernel_vs_torch_cell(N, H):
     np.testing.assert_allclose(ops.gru_gates(gi, gh, h).numpy(), ref.numpy(), atol=TOL, rtol=0)   # host form
 
 
+@pytest.mark.parametrize("tag", ["3j4r_h64", "2j2r_h128", "6j8r_h64"])
+def test_gru_scan_with_in_kernel_input_transform_and_actor(tag):
+    """Static observation: the scan launch computes each sequence's input transform (fc1 -> ReLU -> W_ih) and actor
+    chain itself from the observation row it finds through an index into a [N, T+1, J, S] ring == torch layers on the
+    gathered rows followed by the ordinary scan; the Double-DQN launch then reads one actor row per sequence."""
+    from macjd_amd import ops
+    from macjd_amd.core.networks import RNNAgent
+    g, d = load(tag)
+    args = _gpu_args(d)
+    H, A, J, S = d["H"], d["A"], d["J"], d["S"]
+    torch.manual_seed(2)
+    with quiet():
+        agents = [RNNAgent(S, args).to(DEV), RNNAgent(S, args).to(DEV)]
+    agents[0].load_state_dict(sd_from(g, "agent."))
+    N, T1, B = 40, 13, 9
+    ring = torch.randn(N, T1, J, S, device=DEV)
+    idx = torch.tensor([3, 39, 0, 17, 17, 5, 22, 8, 31], dtype=torch.int64, device=DEV)
+    with torch.no_grad():
+        hs, ps = ops.gru_sequence_from_obs(ring, idx, agents, B, J, T1, with_actor=True)
+        rows0 = ring[idx, 0].reshape(B * J, S)
+        for a, h, p in zip(agents, hs, ps):
+            gi = a.rnn.weight_ih.new_zeros(0)
+            gi = torch.nn.functional.linear(torch.relu(a.fc1(rows0)), a.rnn.weight_ih, a.rnn.bias_ih).view(B, 1, J, 3 * H)
+            ref = ops.gru_sequence_reference(gi.expand(B, T1, J, 3 * H).cpu(), a.rnn.weight_hh.cpu(), a.rnn.bias_hh.cpu())
+            np.testing.assert_allclose(h.cpu().numpy(), ref.numpy(), atol=TOL, rtol=0)
+            np.testing.assert_allclose(p.cpu().numpy(), a.actor(rows0).view(B, J, A).cpu().numpy(), atol=1e-6, rtol=1e-5)
+        if H == 64 and ops.qhead_double_q_fused_supported(hs[0], H, A):
+            heads = [(a.fc2_q_head[0].weight, a.fc2_q_head[0].bias, a.fc2_q_head[2].weight, a.fc2_q_head[2].bias) for a in agents]
+            n = B * T1 * J
+            ex = lambda p_: p_.view(B, 1, J, A).expand(B, T1, J, A).reshape(n, A)
+            a_ = ops.qhead_double_q_from_h(hs[1].reshape(n, H), ps[1], heads[1], hs[0].reshape(n, H), ps[0], heads[0], H, A,
+                                           p_row_map=(T1 * J, J))
+            b_ = ops.qhead_double_q_from_h(hs[1].reshape(n, H), ex(ps[1]), heads[1], hs[0].reshape(n, H), ex(ps[0]), heads[0], H, A)
+            assert torch.equal(a_, b_)
+
+
 def test_gru_sequence_kernel_strided_initial_state():
     """h0 handed over as step 0 of a stored [B, T+1, J, H] tensor (batch stride (T+1) J H): no copy, same result."""
     from macjd_amd import ops
