@@ -292,11 +292,15 @@ class QMixLearner:
         shared = self._body_is_shared()
         agents = [self.mac.agent] if shared else [self.target_mac.agent, self.mac.agent]
         with torch.cuda.stream(ts), torch.no_grad():
-            # (the frozen actor chain of each sequence's observation row rides in the scan launch's prologue as well: a
-            # separate 96-row actor launch costs ~20 us of pure latency, a third stream for it ~30 us of graph-branch
-            # start-up — measured 0.216 -> 0.246 ms / step)
-            h, ps = ops.gru_sequence_from_obs(self._g_buffer.buffers["obs"], self._g_idx, agents, self._g_B, self.n_agents,
-                                              self._g_T + 1, with_actor=True)
+            # (MACJD_ACTOR_IN_SCAN=1: the frozen actor chain of each sequence's observation row rides in the scan launch's
+            # prologue as well.  Off by default: the prologue is on the update's critical path and the origin stream has
+            # slack for the separate actor launch; a third stream for it cost ~30 us of graph-branch start-up,
+            # 0.216 -> 0.246 ms / step)
+            res = ops.gru_sequence_from_obs(self._g_buffer.buffers["obs"], self._g_idx, agents, self._g_B, self.n_agents,
+                                            self._g_T + 1, with_actor=self._g_actor_in_scan)
+            h, ps = res if self._g_actor_in_scan else (res, None)
+        if not self._g_actor_in_scan:
+            return ([h[0], h[0]] if shared else h), None
         return ([h[0], h[0]] if shared else h), ([ps[0], ps[0]] if shared else ps)
 
     def _forward_backward_full(self, st, T, pre_scan=None, pre_actor=None):
@@ -401,10 +405,10 @@ class QMixLearner:
                 if not fused_dq:           # the two-launch Double-DQN form wants one row per (b, t, j)
                     ex = lambda p_: p_.view(B, 1, J, A).expand(B, T1, J, A).reshape(n, A)
                     p_target, p_eval = (None if p_target is None else ex(p_target)), ex(p_eval)
-            else:
-                with torch.no_grad():
-                    p_eval = actor_all(body)
             eval_q_tot = eval_forward()
+            if pre_actor is None:          # only the Double-DQN launches behind the join read it: issued after the eval
+                with torch.no_grad():      # forward, whose autograd chain is the longer part of this stream
+                    p_eval = actor_all(body)
             with torch.no_grad():
                 # unfused mixer: its state-only half (LayerNorm + hyper-networks) runs here, before the join; the fused
                 # mixer is ONE launch that needs the target Q-values, i.e. it runs behind the join
@@ -497,6 +501,7 @@ class QMixLearner:
         self._g_buffer, self._g_B, self._g_T = buffer, int(batch_size), int(buffer.episode_limit)
         # static observations in every stored episode (see _forward_backward_full): baked into the captured launches
         self._g_obs_static = bool(getattr(buffer, "obs_static", False)) and os.environ.get("MACJD_LEARNER_STATIC_OBS", "1") != "0"
+        self._g_actor_in_scan = os.environ.get("MACJD_ACTOR_IN_SCAN", "0") == "1"
         self._g_scan_from_ring = self._g_obs_static and os.environ.get("MACJD_SCAN_FROM_RING", "1") != "0" \
             and int(buffer.buffers["obs"].shape[-1]) <= 3 * int(self.args.rnn_hidden_dim)
         self._g_idx = torch.zeros(self._g_B, dtype=torch.int64, device=self.device)
