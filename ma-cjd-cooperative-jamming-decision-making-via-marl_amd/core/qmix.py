@@ -328,11 +328,16 @@ class QMixLearner:
         # transform and the actor chain — is evaluated on the B * J step-0 rows instead of on all B * (T + 1) * J rows;
         # the scan takes the one input transform per sequence at every step.
         obs_static = bool(getattr(self, "_g_obs_static", False))
-        rows_s = st["obs"][:, 0].reshape(B * J, -1) if obs_static else rows
         Tg = 1 if obs_static else T1
+        rows_cache = []
+
+        def rows_static():   # (a strided slice: the reshape is a copy launch — made where it is first needed, not up front)
+            if not rows_cache:
+                rows_cache.append(st["obs"][:, 0].reshape(B * J, -1) if obs_static else rows)
+            return rows_cache[0]
 
         def actor_all(agent):
-            p = agent.actor_forward(rows_s)                                                    # networks.py:127
+            p = agent.actor_forward(rows_static())                                             # networks.py:127
             return p.view(B, 1, J, A).expand(B, T1, J, A).reshape(n, A) if obs_static else p
 
         # Two streams inside the (captured) update (kernel timeline: scripts/timeline_update.py; the measured
@@ -356,16 +361,16 @@ class QMixLearner:
                 if shared:
                     h_alls = [h_alls[0], h_alls[0]]
             elif shared:
-                gis = [body.gru_input_transform(rows_s).view(B, Tg, J, 3 * H)]                 # networks.py:100
+                gis = [body.gru_input_transform(rows_static()).view(B, Tg, J, 3 * H)]                 # networks.py:100
                 h = ops.gru_sequence_multi(gis, [body.rnn.weight_hh], [body.rnn.bias_hh], n_steps=ns)[0]   # h_0 = 0, qmix.py:241
                 h_alls = [h, h]
             else:
                 a0, a1 = macs[0].agent, macs[1].agent
                 if rows.is_cuda and a0.fused_gi and a1.fused_gi and not torch.is_grad_enabled():
                     # fc1 -> ReLU -> W_ih of both controllers: one launch of the dense-chain kernel
-                    gis = [g.view(B, Tg, J, 3 * H) for g in ops.mlp_forward_pair(rows_s, a0.gi_layers(), rows_s, a1.gi_layers())]
+                    gis = [g.view(B, Tg, J, 3 * H) for g in ops.mlp_forward_pair(rows_static(), a0.gi_layers(), rows_static(), a1.gi_layers())]
                 else:
-                    gis = [m.agent.gru_input_transform(rows_s).view(B, Tg, J, 3 * H) for m in macs]
+                    gis = [m.agent.gru_input_transform(rows_static()).view(B, Tg, J, 3 * H) for m in macs]
                 h_alls = ops.gru_sequence_multi(gis, [m.agent.rnn.weight_hh for m in macs],
                                                 [m.agent.rnn.bias_hh for m in macs], n_steps=ns)
             if fused_dq:   # the Double-DQN launch takes the hidden states themselves (its base products run on MFMA)

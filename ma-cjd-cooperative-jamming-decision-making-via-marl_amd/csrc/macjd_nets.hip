@@ -319,40 +319,49 @@ __global__ void __launch_bounds__(64 * NW) gru_sequence_kernel(const macjd_gru_i
         const int S = io.S;
         for (int k = threadIdx.x; k < S; k += 64 * NW) xs[k] = x[k];
         __syncthreads();
-        // (eight outputs per wave and pass, all their weight elements requested before the first is used: one output at
-        // a time is one memory latency per output — 75 us for the five layers)
+        // (UN outputs per wave and pass, all their weight elements requested before the first is used — one output at a
+        // time is one memory latency per output, 75 us for the five layers; NCH = ceil(K / 64) k-chunks per lane, a
+        // compile-time count so that no load sits behind a branch)
         auto matvec = [&](const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ vin, int K,
                           int N, auto&& store) {   // store(o, value) for o in [0, N)
-            constexpr int UN = 8;
-            for (int o0 = wave * UN; o0 < N; o0 += NW * UN) {
-                float wv[UN][4], a[UN];
+            auto body = [&](auto nch_c) {
+                constexpr int NCH = decltype(nch_c)::value;
+                constexpr int UN = 16 / NCH;          // 16 loads in flight per lane
+                float xv[NCH];
 #pragma unroll
-                for (int uu = 0; uu < UN; ++uu) {
-                    const int o = (o0 + uu < N) ? o0 + uu : N - 1;        // clamped: no branch around the loads
-                    const float* wr = W + (int64_t)o * K;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int k = lane + 64 * c;
-                        wv[uu][c] = wr[k < K ? k : K - 1];
-                    }
-                }
-                float xv[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
+                for (int c = 0; c < NCH; ++c) {
                     const int k = lane + 64 * c;
                     xv[c] = (k < K) ? vin[k] : 0.0f;
                 }
+                for (int o0 = wave * UN; o0 < N; o0 += NW * UN) {
+                    float wv[UN][NCH], a[UN];
 #pragma unroll
-                for (int uu = 0; uu < UN; ++uu) {
-                    float t = 0.0f;
+                    for (int uu = 0; uu < UN; ++uu) {
+                        const int o = (o0 + uu < N) ? o0 + uu : N - 1;        // clamped: no branch around the loads
+                        const float* wr = W + (int64_t)o * K;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) t = fmaf(wv[uu][c], xv[c], t);   // zero x past K
-                    a[uu] = wave_sum(t);
+                        for (int c = 0; c < NCH; ++c) {
+                            const int k = lane + 64 * c;
+                            wv[uu][c] = wr[k < K ? k : K - 1];
+                        }
+                    }
+#pragma unroll
+                    for (int uu = 0; uu < UN; ++uu) {
+                        float t = 0.0f;
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) t = fmaf(wv[uu][c], xv[c], t);   // x is zero past K
+                        a[uu] = wave_sum(t);
+                    }
+                    float mine = 0.0f;
+#pragma unroll
+                    for (int uu = 0; uu < UN; ++uu) mine = (lane == uu) ? a[uu] : mine;
+                    if (lane < UN && o0 + lane < N) store(o0 + lane, mine + bias[o0 + lane]);
                 }
-#pragma unroll
-                for (int uu = 0; uu < UN; ++uu)
-                    if (lane == uu && o0 + uu < N) store(o0 + uu, a[uu] + bias[o0 + uu]);
-            }
+            };
+            const int nch = (K + 63) / 64;
+            if (nch == 1) body(std::integral_constant<int, 1>{});
+            else if (nch == 2) body(std::integral_constant<int, 2>{});
+            else body(std::integral_constant<int, 4>{});
         };
         matvec(io.fc1_w[net], io.fc1_b[net], xs, S, H, [&](int o, float v) { v1[o] = fmaxf(v, 0.0f); });
         __syncthreads();
