@@ -329,12 +329,9 @@ class QMixLearner:
         # the scan takes the one input transform per sequence at every step.
         obs_static = bool(getattr(self, "_g_obs_static", False))
         Tg = 1 if obs_static else T1
-        rows_cache = []
 
-        def rows_static():   # (a strided slice: the reshape is a copy launch — made where it is first needed, not up front)
-            if not rows_cache:
-                rows_cache.append(st["obs"][:, 0].reshape(B * J, -1) if obs_static else rows)
-            return rows_cache[0]
+        def rows_static():   # (a strided slice: the reshape is a copy launch — made on the stream and at the point where
+            return st["obs"][:, 0].reshape(B * J, -1) if obs_static else rows   # it is needed, not up front)
 
         def actor_all(agent):
             p = agent.actor_forward(rows_static())                                             # networks.py:127
