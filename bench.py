@@ -95,27 +95,29 @@ def cpu_baseline(sc, E, seed, budget_s=12.0):
     return out
 
 
-def pmc_traffic(J, R, E, per_env=False):
+def pmc_traffic(J, R, E, per_env=False, many=False):
     """HBM bytes per env_step launch from the committed rocprofv3 PMC summary (profiles/), collected in
-    separate --pmc passes and corrected as MI355X_MICROARCH.md prescribes; None when no matching run."""
+    separate --pmc passes and corrected as MI355X_MICROARCH.md prescribes; None when no matching run.
+    ``many``: the many-step launch (key "many_<E>" of the summary)."""
     import glob
+    key = f"many_{E}" if many else str(E)
     for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_env_step*_pmc.json")), reverse=True):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("kernel", "").endswith(f"<{J},{R},per-env>" if per_env else f"<{J},{R}>") and str(E) in d.get("runs", {}):
-            return d["runs"][str(E)]["traffic_bytes_per_launch"], os.path.basename(f)
+        if d.get("kernel", "").endswith(f"<{J},{R},per-env>" if per_env else f"<{J},{R}>") and key in d.get("runs", {}):
+            return d["runs"][key]["traffic_bytes_per_launch"], os.path.basename(f)
     return None, None
 
 
-def profiled_kernel_time(kernel_substr, per_env=False):
+def profiled_kernel_time(kernel_substr, per_env=False, pattern=None):
     """(average us, min us, calls, file) of a kernel in the latest committed rocprofv3 --kernel-trace --stats summary of
     the env-roofline replay (scripts/collect_profiles.sh: `bench.py --mode env --steps 1 --warmup 0`, i.e. the 200-launch
     graph of macjd_env_step_timed, warm + timed); None when no such file."""
     import csv
     import glob
-    pat = "r*_bench_env_per_env_kernel_stats.csv" if per_env else "r*_bench_env_roofline_kernel_stats.csv"
+    pat = pattern or ("r*_bench_env_per_env_kernel_stats.csv" if per_env else "r*_bench_env_roofline_kernel_stats.csv")
     for f in sorted(glob.glob(os.path.join(REPO, "profiles", pat)), reverse=True):
         try:
             for r in csv.DictReader(open(f)):
@@ -272,26 +274,55 @@ def main():
             torch.cuda.synchronize()
 
     # ---- roofline of the env-step kernel: HIP events on the launch stream ----
+    # (1) the launch the rollout / train modes actually issue: ONE launch for the T = episode_limit steps of all E envs
+    #     (macjd_env_step_many: T x E independent work items in the streaming lane kernel; no pd / snr_with outputs,
+    #     `track` and the counters written once per env).  (2) the single-step launch of the step-by-step API at the
+    #     same E (what `mode: env` issues; launch-latency bound).  (3) below: the 2^22-env streaming point.
     ms = env.time_step_kernel(T, P, iters=200)
     B_step = algorithmic_bytes_per_env_step(J, R, uniforms_supplied=False) + (per_env_table_bytes(J, R) if args.per_env else 0)
     achieved = E * B_step / (ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(J, R, E, args.per_env)[0],
-                "traffic_source": pmc_traffic(J, R, E, args.per_env)[1],
-                "kernel": (f"env_step_kernel<{J},{R},per-env tables>" if args.per_env else
-                           f"env_step_slots_kernel<{J},{R}>" if E < (1 << 16) else f"env_step_kernel<{J},{R}>"),
-                "us_per_launch": round(ms * 1e3, 3),
-                "timing": "HIP events around 200 launches replayed from one HIP graph on their own stream (macjd_env_step_timed); "
-                          "the rocprofv3 kernel-trace average of the same replay is committed under profiles/ (r02_bench_env_roofline_*)",
-                "traffic_measured_in_run": False,
-                "bytes_per_env_step": B_step, "envs_per_launch": E}
+    kname = (f"env_step_kernel<{J},{R},per-env tables>" if args.per_env else
+             f"env_step_slots_kernel<{J},{R}>" if E < (1 << 16) else f"env_step_kernel<{J},{R}>")
+    single = {"kernel": kname, "us_per_launch": round(ms * 1e3, 3), "achieved": round(achieved, 3),
+              "frac": round(achieved / HBM_PEAK_GBS, 6), "bytes_per_env_step": B_step, "envs_per_launch": E,
+              "traffic": pmc_traffic(J, R, E, args.per_env)[0], "traffic_source": pmc_traffic(J, R, E, args.per_env)[1]}
     prof = profiled_kernel_time("env_step_kernel<" if (args.per_env or E >= (1 << 16)) else "env_step_slots_kernel<", args.per_env)
     if prof is not None and E == 4096:
         # the committed rocprofv3 summary of the same replay: its per-dispatch duration (start -> end timestamps of ONE
         # dispatch, taken with the dispatches serialised by the profiler) is ~0.7 us above the back-to-back figure the
         # HIP events give for a launch this short; both are stated, `frac` uses the live HIP-event time
-        roofline["profile"] = {"file": prof[3], "avg_us": round(prof[0], 3), "min_us": round(prof[1], 3), "calls": prof[2],
-                               "frac_from_avg": round(E * B_step / (prof[0] * 1e-6) / 1e9 / HBM_PEAK_GBS, 6)}
+        single["profile"] = {"file": prof[3], "avg_us": round(prof[0], 3), "min_us": round(prof[1], 3), "calls": prof[2],
+                             "frac_from_avg": round(E * B_step / (prof[0] * 1e-6) / 1e9 / HBM_PEAK_GBS, 6)}
+    Tn = sc.episode_limit
+    Tm = torch.randint(0, 2 * R + 1, (Tn, E, J), generator=g, device=dev, dtype=torch.int32)
+    Pm = torch.rand((Tn, E, J), generator=g, device=dev)
+    rew_m = torch.zeros((Tn, E), device=dev)
+    ter_m = torch.zeros((Tn, E), dtype=torch.uint8, device=dev)
+    rd_m = torch.zeros((Tn, E, 3), device=dev)
+    env.time_step_many_kernel(Tm, Pm, rew_m, ter_m, rd_m, iters=3)
+    ms_m = env.time_step_many_kernel(Tm, Pm, rew_m, ter_m, rd_m, iters=50)
+    # algorithmic bytes per env-step of THIS launch: T 4J + P 4J + step 4 + episode 4 read, reward 4 + (r_d,r_p,r_j) 12 +
+    # terminated 1 written; track R + step 4 are written once per env (1 / T per env-step); per-env tables are read by
+    # every step's work item
+    B_many = 8 * J + 4 + 4 + 4 + 12 + 1 + (R + 4) / Tn + (per_env_table_bytes(J, R) if args.per_env else 0)
+    ach_m = Tn * E * B_many / (ms_m * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": round(ach_m, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach_m / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(J, R, E, args.per_env, many=True)[0],
+                "traffic_source": pmc_traffic(J, R, E, args.per_env, many=True)[1],
+                "kernel": f"env_step_kernel<{J},{R}" + (",per-env tables" if args.per_env else "") +
+                          f"> as launched by the rollout: {Tn} steps x {E} envs = {Tn * E} work items per launch (macjd_env_step_many)",
+                "us_per_launch": round(ms_m * 1e3, 3),
+                "timing": "HIP events around 50 launches replayed from one HIP graph on their own stream (macjd_env_step_many_timed); "
+                          "the rocprofv3 kernel-trace summary of the rollout (profiles/r02*_bench_rollout_kernel_stats.csv) has the same kernel",
+                "traffic_measured_in_run": False,
+                "bytes_per_env_step": round(B_many, 2), "env_steps_per_launch": Tn * E,
+                "single_step_launch": single}
+    prof_m = profiled_kernel_time("env_step_kernel<", args.per_env, pattern="r*_bench_rollout_kernel_stats.csv")
+    if prof_m is not None and E == 4096 and not args.per_env:
+        roofline["profile"] = {"file": prof_m[3], "avg_us": round(prof_m[0], 3), "min_us": round(prof_m[1], 3), "calls": prof_m[2],
+                               "note": "rollout-mode trace: the many-step launches plus bench.py's 2^22-env roofline launches share "
+                                       "this kernel name; min_us is the many-step launch"}
+    del Tm, Pm, rew_m, ter_m, rd_m
     # large-batch point of the same kernel family (2^22 envs): the HBM-bound asymptote, measured every run so the
     # launch-bound fraction at the benchmark's E is not mistaken for the kernel's streaming rate
     if rank == 0:

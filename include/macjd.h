@@ -201,6 +201,11 @@ int macjd_env_step_many(const macjd_scenario* s, const macjd_step_io* io, int32_
 int macjd_env_step_timed(const macjd_scenario* s, const macjd_step_io* io, int iters,
                          void* hip_stream, float* ms_per_launch);
 
+/* the same for the main kernel of macjd_env_step_many (n_steps x n_envs work items per launch; the counter-advance
+   launch is not part of the replayed graph, so every replay does identical work) */
+int macjd_env_step_many_timed(const macjd_scenario* s, const macjd_step_io* io, int32_t n_steps, int64_t t_stride,
+                              int iters, void* hip_stream, float* ms_per_launch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,7 +27,7 @@ EXPORTS = [
     "macjd_mlp_forward", "macjd_mlp_forward_pair", "macjd_td_loss", "macjd_clip_adam_step", "macjd_gather_rows",
     "macjd_linear_wgrad", "macjd_linear_wgrad_workspace_floats", "macjd_linear_wgrad_many", "macjd_qhead_input", "macjd_layernorm_forward", "macjd_layernorm_param_grad", "macjd_gru_gates", "macjd_rowdot", "macjd_splitrelu_backward",
     "macjd_mixer_fused_supported", "macjd_mixer_fused_forward", "macjd_mixer_fused_backward",
-    "macjd_agent_episode_supported", "macjd_agent_episode", "macjd_env_step_many",
+    "macjd_agent_episode_supported", "macjd_agent_episode", "macjd_env_step_many", "macjd_env_step_many_timed",
     "macjd_qhead_double_q_supported", "macjd_qhead_double_q",
 ]
 
@@ -311,6 +311,9 @@ def load() -> ctypes.CDLL:
     lib.macjd_agent_episode.argtypes = [ctypes.POINTER(AgentEpisodeIO), ctypes.c_void_p]
     lib.macjd_env_step_many.restype = ctypes.c_int
     lib.macjd_env_step_many.argtypes = [ctypes.c_void_p, ctypes.POINTER(StepIO), ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p]
+    lib.macjd_env_step_many_timed.restype = ctypes.c_int
+    lib.macjd_env_step_many_timed.argtypes = [ctypes.c_void_p, ctypes.POINTER(StepIO), ctypes.c_int32, ctypes.c_int64, ctypes.c_int,
+                                              ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
     lib.macjd_mixer_fused_supported.restype = ctypes.c_int
     lib.macjd_mixer_fused_supported.argtypes = [ctypes.c_int32] * 4
     for name in ("macjd_mixer_fused_forward", "macjd_mixer_fused_backward"):

@@ -993,8 +993,22 @@ int macjd_env_step_many(const macjd_scenario* s, const macjd_step_io* io, int32_
     return MACJD_OK;
 }
 
+static int env_step_timed_impl(const macjd_scenario* s, const macjd_step_io* io, int iters, void* hip_stream,
+                               float* ms_per_launch, int32_t many_T, int64_t t_stride);
+
 int macjd_env_step_timed(const macjd_scenario* s, const macjd_step_io* io, int iters, void* hip_stream,
                          float* ms_per_launch) {
+    return env_step_timed_impl(s, io, iters, hip_stream, ms_per_launch, 0, 0);
+}
+
+int macjd_env_step_many_timed(const macjd_scenario* s, const macjd_step_io* io, int32_t n_steps, int64_t t_stride, int iters,
+                              void* hip_stream, float* ms_per_launch) {
+    if (n_steps < 1 || t_stride < 0) return set_err(MACJD_EINVAL, "%s", "macjd_env_step_many_timed: bad n_steps / t_stride");
+    return env_step_timed_impl(s, io, iters, hip_stream, ms_per_launch, n_steps, t_stride);
+}
+
+static int env_step_timed_impl(const macjd_scenario* s, const macjd_step_io* io, int iters, void* hip_stream,
+                               float* ms_per_launch, int32_t many_T, int64_t t_stride) {
     int rc = validate_io(s, io);
     if (rc != MACJD_OK) return rc;
     if (iters < 1 || !ms_per_launch) return set_err(MACJD_EINVAL, "macjd_env_step_timed: bad iters / output");
@@ -1016,7 +1030,7 @@ int macjd_env_step_timed(const macjd_scenario* s, const macjd_step_io* io, int i
     if (hipStreamSynchronize(stream) == hipSuccess && hipStreamCreateWithFlags(&priv, hipStreamNonBlocking) == hipSuccess) {
         if (hipStreamBeginCapture(priv, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             int crc = MACJD_OK;
-            for (int i = 0; i < iters && crc == MACJD_OK; ++i) crc = launch_step(s, io, priv);
+            for (int i = 0; i < iters && crc == MACJD_OK; ++i) crc = launch_step(s, io, priv, many_T, t_stride);
             const hipError_t ce = hipStreamEndCapture(priv, &graph);
             if (ce == hipSuccess && crc == MACJD_OK && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess)
                 graphed = hipGraphLaunch(exec, priv) == hipSuccess && hipStreamSynchronize(priv) == hipSuccess;   // warm
@@ -1028,7 +1042,7 @@ int macjd_env_step_timed(const macjd_scenario* s, const macjd_step_io* io, int i
     if (graphed) {
         if (hipGraphLaunch(exec, stream) != hipSuccess) rc = set_err(MACJD_EDEVICE, "%s", "macjd_env_step_timed: graph launch failed");
     } else {
-        for (int i = 0; i < iters && rc == MACJD_OK; ++i) rc = launch_step(s, io, stream);
+        for (int i = 0; i < iters && rc == MACJD_OK; ++i) rc = launch_step(s, io, stream, many_T, t_stride);
     }
     (void)hipEventRecord(t1, stream);
     err = hipEventSynchronize(t1);

@@ -306,6 +306,22 @@ class BatchedElectromagneticEnvironment:
         io.r_dpj = self._r_dpj.data_ptr()
         self._keep = (actions_T, actions_P, out_reward, out_terminated, out_rdpj)
 
+    def time_step_many_kernel(self, actions_T, actions_P, out_reward, out_terminated, out_rdpj, iters: int) -> float:
+        """bench.py helper: average milliseconds per launch of the many-step kernel (n x E work items), ``iters``
+        launches replayed from a HIP graph and bracketed by HIP events on the replay stream (macjd_env_step_many_timed)."""
+        E, J = self.batch_envs, self.num_jammers
+        n = actions_T.shape[0]
+        io = self._fill_io(actions_T[0].view(E, J), actions_P[0].view(E, J), None, False, out_reward.view(-1)[:E],
+                           out_terminated.view(-1)[:E], False, None, None)
+        io.r_dpj = out_rdpj.data_ptr()
+        ms = ctypes.c_float(0.0)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            _native.check(self._lib.macjd_env_step_many_timed(self._handle.ptr, ctypes.byref(io), int(n), int(E * J), int(iters),
+                                                              stream, ctypes.byref(ms)), "macjd_env_step_many_timed")
+        io.r_dpj = self._r_dpj.data_ptr()
+        return float(ms.value)
+
     def time_step_kernel(self, actions_T: torch.Tensor, actions_P: torch.Tensor, iters: int,
                          uniforms: Optional[torch.Tensor] = None, want_info: bool = True) -> float:
         """bench.py helper: average milliseconds per env_step launch over ``iters`` back-to-back

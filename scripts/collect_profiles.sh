@@ -41,6 +41,10 @@ for E in 4096 4194304; do
     echo "[collect] pmc E=$E $C"
   done
 done
+for C in FETCH_SIZE WRITE_SIZE; do   # the rollout's many-step env launch
+  timeout -k 10 300 rocprofv3 --pmc $C -d $D/MANY_$C -o p --output-format csv -- python3 $ROOT/bench.py --mode rollout --steps 300 --warmup 100 --no-cpu-baseline --no-other-modes > /dev/null 2>&1
+  echo "[collect] pmc many-step $C"
+done
 python3 $ROOT/scripts/pmc_env_summary.py $D $TAG > $OUT/${TAG}_env_step_pmc.json
 rm -rf $D
 # per-env tables: ONE pass per counter at the default E = 4096; the 2^22-env launches come from bench.py's large_batch

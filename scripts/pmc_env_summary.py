@@ -42,6 +42,28 @@ for E, kern in ((4096, "env_step_kernel" if per_env else "env_step_slots_kernel"
         rec["traffic_over_algorithmic"] = round(rec["traffic_bytes_per_launch"] / (E * B_ALG), 4)
         rec["kernel_name"] = kern
         runs[str(E)] = rec
+# the many-step launch of the rollout (macjd_env_step_many: T x E work items in the lane kernel): passes MANY_<ctr> of
+# `bench.py --mode rollout`, dispatches recognised by their grid size
+if not per_env:
+    T_STEPS, E0 = 100, 4096
+    B_MANY = 8 * J + 4 + 4 + 4 + 12 + 1 + (R + 4) / T_STEPS
+    rec = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        vals = []
+        for f in glob.glob(os.path.join(out, f"MANY_{ctr}", "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "env_step_kernel<" in r["Kernel_Name"] and r["Counter_Name"] == ctr and \
+                        T_STEPS * E0 <= int(r["Grid_Size"]) < T_STEPS * E0 + 256:
+                    vals.append(float(r["Counter_Value"]))
+        if vals:
+            rec[f"{ctr}_KB_median"], rec[f"{ctr}_n"] = statistics.median(vals), len(vals)
+    if len(rec) == 4:
+        rec["traffic_bytes_per_launch"] = int((2 * rec["FETCH_SIZE_KB_median"] + rec["WRITE_SIZE_KB_median"]) * 1024)
+        rec["algorithmic_bytes_per_launch"] = int(T_STEPS * E0 * B_MANY)
+        rec["traffic_over_algorithmic"] = round(rec["traffic_bytes_per_launch"] / (T_STEPS * E0 * B_MANY), 4)
+        rec["kernel_name"] = "env_step_kernel (many-step launch: 100 steps x 4096 envs)"
+        rec["bytes_per_env_step_algorithmic"] = round(B_MANY, 2)
+        runs[f"many_{E0}"] = rec
 print(json.dumps({
     "round": tag, "kernel": f"macjd::env_step_kernel<{J},{R},per-env>" if per_env else f"macjd::env_step_slots_kernel<{J},{R}>",
     "workload": f"{J} jammers / {R} radars, Philox in-kernel, info outputs on" + (", per-env scenario tables" if per_env else ""),
