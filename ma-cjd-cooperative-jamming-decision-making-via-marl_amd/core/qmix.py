@@ -292,10 +292,10 @@ class QMixLearner:
         shared = self._body_is_shared()
         agents = [self.mac.agent] if shared else [self.target_mac.agent, self.mac.agent]
         with torch.cuda.stream(ts), torch.no_grad():
-            # (MACJD_ACTOR_IN_SCAN=1: the frozen actor chain of each sequence's observation row rides in the scan launch's
-            # prologue as well.  Off by default: the prologue is on the update's critical path and the origin stream has
-            # slack for the separate actor launch; a third stream for it cost ~30 us of graph-branch start-up,
-            # 0.216 -> 0.246 ms / step)
+            # (the frozen actor chain of each sequence's observation row rides in the scan launch's prologue as well.
+            # With the K-split scan (65 us) the prologue was on the update's critical path and the separate actor launch
+            # on the origin stream was the better place; since the unit-split scan (27 us) the origin stream is the
+            # longer branch: 0.220 -> 0.192 ms / step.  MACJD_ACTOR_IN_SCAN=0 keeps the separate launch.)
             res = ops.gru_sequence_from_obs(self._g_buffer.buffers["obs"], self._g_idx, agents, self._g_B, self.n_agents,
                                             self._g_T + 1, with_actor=self._g_actor_in_scan)
             h, ps = res if self._g_actor_in_scan else (res, None)
@@ -503,7 +503,7 @@ class QMixLearner:
         self._g_buffer, self._g_B, self._g_T = buffer, int(batch_size), int(buffer.episode_limit)
         # static observations in every stored episode (see _forward_backward_full): baked into the captured launches
         self._g_obs_static = bool(getattr(buffer, "obs_static", False)) and os.environ.get("MACJD_LEARNER_STATIC_OBS", "1") != "0"
-        self._g_actor_in_scan = os.environ.get("MACJD_ACTOR_IN_SCAN", "0") == "1"
+        self._g_actor_in_scan = os.environ.get("MACJD_ACTOR_IN_SCAN", "1") != "0"
         self._g_scan_from_ring = self._g_obs_static and os.environ.get("MACJD_SCAN_FROM_RING", "1") != "0" \
             and int(buffer.buffers["obs"].shape[-1]) <= 3 * int(self.args.rnn_hidden_dim)
         self._g_idx = torch.zeros(self._g_B, dtype=torch.int64, device=self.device)

@@ -19,6 +19,8 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 #include "../../include/macjd.h"
@@ -259,6 +261,84 @@ __device__ __forceinline__ float gru_tanh(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
 }
 
+// Prologue of the scan kernels for a static observation (macjd_gru_io.obs); results: s_gi [3H] in LDS and, when asked,
+// io.p_out.  All NW waves of the workgroup take part; ends with a barrier.
+template <int H, int NW>
+__device__ __forceinline__ void scan_prologue(const macjd_gru_io& io, const int net, const int b, const int j,
+                                              float* __restrict__ s_pro, float* __restrict__ s_gi, const int lane,
+                                              const int wave) {
+    // Prologue for a static observation: this sequence's ONE observation row x -> gi = W_ih ReLU(fc1 x + b) + b_ih
+    // and, when asked, the actor chain sigmoid(L3 ReLU(L2 ReLU(L1 x))).  Small mat-vecs on the VALU: an output is a
+    // wave-wide dot product (lanes split k: every weight row is read as coalesced 256-B pieces from L2), outputs are
+    // dealt round-robin to the NW waves; layers meet in LDS.
+    float* xs = s_pro;              // [S]
+    float* v1 = s_pro + 256;        // [<= 256] first hidden vector
+    float* v2 = s_pro + 512;        // [<= 256] second hidden vector
+    const int64_t row = io.obs_index ? io.obs_index[b] : (int64_t)b;
+    const float* x = io.obs + row * io.obs_sb + (int64_t)j * io.obs_sj;
+    const int S = io.S;
+    for (int k = threadIdx.x; k < S; k += 64 * NW) xs[k] = x[k];
+    __syncthreads();
+    // (UN outputs per wave and pass, all their weight elements requested before the first is used — one output at a
+    // time is one memory latency per output, 75 us for the five layers; NCH = ceil(K / 64) k-chunks per lane, a
+    // compile-time count so that no load sits behind a branch)
+    auto matvec = [&](const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ vin, int K,
+                      int N, auto&& store) {   // store(o, value) for o in [0, N)
+        auto body = [&](auto nch_c) {
+            constexpr int NCH = decltype(nch_c)::value;
+            constexpr int UN = 16 / NCH;          // 16 loads in flight per lane
+            float xv[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int k = lane + 64 * c;
+                xv[c] = (k < K) ? vin[k] : 0.0f;
+            }
+            for (int o0 = wave * UN; o0 < N; o0 += NW * UN) {
+                float wv[UN][NCH], a[UN];
+#pragma unroll
+                for (int uu = 0; uu < UN; ++uu) {
+                    const int o = (o0 + uu < N) ? o0 + uu : N - 1;        // clamped: no branch around the loads
+                    const float* wr = W + (int64_t)o * K;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        const int k = lane + 64 * c;
+                        wv[uu][c] = wr[k < K ? k : K - 1];
+                    }
+                }
+#pragma unroll
+                for (int uu = 0; uu < UN; ++uu) {
+                    float t = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) t = fmaf(wv[uu][c], xv[c], t);   // x is zero past K
+                    a[uu] = wave_sum(t);
+                }
+                float mine = 0.0f;
+#pragma unroll
+                for (int uu = 0; uu < UN; ++uu) mine = (lane == uu) ? a[uu] : mine;
+                if (lane < UN && o0 + lane < N) store(o0 + lane, mine + bias[o0 + lane]);
+            }
+        };
+        const int nch = (K + 63) / 64;
+        if (nch == 1) body(std::integral_constant<int, 1>{});
+        else if (nch == 2) body(std::integral_constant<int, 2>{});
+        else body(std::integral_constant<int, 4>{});
+    };
+    matvec(io.fc1_w[net], io.fc1_b[net], xs, S, H, [&](int o, float v) { v1[o] = fmaxf(v, 0.0f); });
+    __syncthreads();
+    matvec(io.w_ih[net], io.b_ih[net], v1, H, 3 * H, [&](int o, float v) { s_gi[o] = v; });
+    if (io.p_out[net]) {
+        const int Ah = io.Ah, A = io.A;
+        __syncthreads();    // v1 is read by the W_ih product above: done before it is overwritten
+        matvec(io.act_w[net][0], io.act_b[net][0], xs, S, Ah, [&](int o, float v) { v1[o] = fmaxf(v, 0.0f); });
+        __syncthreads();
+        matvec(io.act_w[net][1], io.act_b[net][1], v1, Ah, Ah, [&](int o, float v) { v2[o] = fmaxf(v, 0.0f); });
+        __syncthreads();
+        float* po = io.p_out[net] + ((int64_t)b * io.J + j) * A;
+        matvec(io.act_w[net][2], io.act_b[net][2], v2, Ah, A, [&](int o, float v) { po[o] = 1.0f / (1.0f + expf(-v)); });
+    }
+    __syncthreads();
+}
+
 template <int H, int NW>
 __global__ void __launch_bounds__(64 * NW) gru_sequence_kernel(const macjd_gru_io io) {
     constexpr int U = H / 64;    // hidden units per lane
@@ -306,78 +386,7 @@ __global__ void __launch_bounds__(64 * NW) gru_sequence_kernel(const macjd_gru_i
     // io.reserved != 0 ("gi_static"): gi is [B, 1, J, 3H], the same input transform at every step (static observation)
     const bool gi_inkernel = io.obs != nullptr;
     const bool gi_static = io.reserved != 0 || gi_inkernel;
-    if (gi_inkernel) {
-        // Prologue for a static observation: this sequence's ONE observation row x -> gi = W_ih ReLU(fc1 x + b) + b_ih
-        // and, when asked, the actor chain sigmoid(L3 ReLU(L2 ReLU(L1 x))).  Small mat-vecs on the VALU: an output is a
-        // wave-wide dot product (lanes split k: every weight row is read as coalesced 256-B pieces from L2), outputs are
-        // dealt round-robin to the NW waves; layers meet in LDS.
-        float* xs = s_pro;              // [S]
-        float* v1 = s_pro + 256;        // [<= 256] first hidden vector
-        float* v2 = s_pro + 512;        // [<= 256] second hidden vector
-        const int64_t row = io.obs_index ? io.obs_index[b] : (int64_t)b;
-        const float* x = io.obs + row * io.obs_sb + (int64_t)j * io.obs_sj;
-        const int S = io.S;
-        for (int k = threadIdx.x; k < S; k += 64 * NW) xs[k] = x[k];
-        __syncthreads();
-        // (UN outputs per wave and pass, all their weight elements requested before the first is used — one output at a
-        // time is one memory latency per output, 75 us for the five layers; NCH = ceil(K / 64) k-chunks per lane, a
-        // compile-time count so that no load sits behind a branch)
-        auto matvec = [&](const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ vin, int K,
-                          int N, auto&& store) {   // store(o, value) for o in [0, N)
-            auto body = [&](auto nch_c) {
-                constexpr int NCH = decltype(nch_c)::value;
-                constexpr int UN = 16 / NCH;          // 16 loads in flight per lane
-                float xv[NCH];
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    const int k = lane + 64 * c;
-                    xv[c] = (k < K) ? vin[k] : 0.0f;
-                }
-                for (int o0 = wave * UN; o0 < N; o0 += NW * UN) {
-                    float wv[UN][NCH], a[UN];
-#pragma unroll
-                    for (int uu = 0; uu < UN; ++uu) {
-                        const int o = (o0 + uu < N) ? o0 + uu : N - 1;        // clamped: no branch around the loads
-                        const float* wr = W + (int64_t)o * K;
-#pragma unroll
-                        for (int c = 0; c < NCH; ++c) {
-                            const int k = lane + 64 * c;
-                            wv[uu][c] = wr[k < K ? k : K - 1];
-                        }
-                    }
-#pragma unroll
-                    for (int uu = 0; uu < UN; ++uu) {
-                        float t = 0.0f;
-#pragma unroll
-                        for (int c = 0; c < NCH; ++c) t = fmaf(wv[uu][c], xv[c], t);   // x is zero past K
-                        a[uu] = wave_sum(t);
-                    }
-                    float mine = 0.0f;
-#pragma unroll
-                    for (int uu = 0; uu < UN; ++uu) mine = (lane == uu) ? a[uu] : mine;
-                    if (lane < UN && o0 + lane < N) store(o0 + lane, mine + bias[o0 + lane]);
-                }
-            };
-            const int nch = (K + 63) / 64;
-            if (nch == 1) body(std::integral_constant<int, 1>{});
-            else if (nch == 2) body(std::integral_constant<int, 2>{});
-            else body(std::integral_constant<int, 4>{});
-        };
-        matvec(io.fc1_w[net], io.fc1_b[net], xs, S, H, [&](int o, float v) { v1[o] = fmaxf(v, 0.0f); });
-        __syncthreads();
-        matvec(io.w_ih[net], io.b_ih[net], v1, H, 3 * H, [&](int o, float v) { s_gi[o] = v; });
-        if (io.p_out[net]) {
-            const int Ah = io.Ah, A = io.A;
-            __syncthreads();    // v1 is read by the W_ih product above: done before it is overwritten
-            matvec(io.act_w[net][0], io.act_b[net][0], xs, S, Ah, [&](int o, float v) { v1[o] = fmaxf(v, 0.0f); });
-            __syncthreads();
-            matvec(io.act_w[net][1], io.act_b[net][1], v1, Ah, Ah, [&](int o, float v) { v2[o] = fmaxf(v, 0.0f); });
-            __syncthreads();
-            float* po = io.p_out[net] + ((int64_t)b * io.J + j) * A;
-            matvec(io.act_w[net][2], io.act_b[net][2], v2, Ah, A, [&](int o, float v) { po[o] = 1.0f / (1.0f + expf(-v)); });
-        }
-        __syncthreads();
-    }
+    if (gi_inkernel) scan_prologue<H, NW>(io, net, b, j, s_pro, s_gi, lane, wave);
     auto gi_row = [&](int t) -> const float* {
         return gi_inkernel ? (const float*)s_gi
                            : gi_static ? gi + ((int64_t)b * io.J + j) * (3 * H)
@@ -465,6 +474,125 @@ __global__ void __launch_bounds__(64 * NW) gru_sequence_kernel(const macjd_gru_i
     }
 }
 
+
+// H = 64, second form of the scan: the four waves split the hidden UNITS, the four lanes of a quad split K.
+// Lane l of wave w owns unit u = 16 w + (l >> 2) and the K-quarter [16 (l & 3), +16): 48 weights in VGPRs, the quarter of
+// h arrives as four ds_read_b128 (four distinct addresses per wave, 64 B apart: conflict-free broadcasts), 24 packed FMAs
+// (v_pk_fma_f32) form the three partial gate sums, the four lanes of a quad meet through two DPP adds (quad_perm:
+// v_add_f32_dpp, no LDS round trip, every lane gets the total), every lane of the quad evaluates the gates of its unit
+// (bit-identical copies) and lane 0 of the quad publishes h' in the other half of a double-buffered 256-B LDS vector:
+// ONE barrier per step, like the K-split form above, but 24 + 6 instead of 64 + ~30 instructions in front of the gates
+// and 4 instead of 12 LDS reads behind the barrier (the K-split form pays 16 v_readlane -> SGPR -> FMA hand-overs per
+// wave and step, and sums NW partials per gate).  96 sequences x 101 steps: 56 -> 32 us.
+typedef float float2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float quad_sum(float x) {
+    // x + x[lane ^ 1], then + [lane ^ 2]: quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E
+    x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0xB1, 0xF, 0xF, false));
+    x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x4E, 0xF, 0xF, false));
+    return x;
+}
+// tanh(x) = 1 - 2 / (2^(x 2 log2 e) + 1) with the constants folded: 5 dependent instructions (gru_tanh above: 7)
+__device__ __forceinline__ float gru_tanh_folded(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+}
+
+template <bool STATIC>
+__global__ void __launch_bounds__(256) gru_sequence_units_kernel(const macjd_gru_io io) {
+    constexpr int H = 64, NW = 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane & 3;                // K-quarter
+    const int u = 16 * wave + (lane >> 2); // hidden unit
+    const int net = blockIdx.y;
+    const int seq = blockIdx.x;  // b * J + j
+    const int b = seq / io.J, j = seq - b * io.J;
+    const int T = io.T;
+    const float* __restrict__ gi = io.gi[net];
+    const float* __restrict__ whh = io.w_hh[net];
+    const float* __restrict__ bhh = io.b_hh[net];
+    float* __restrict__ out = io.h_out[net];
+
+    __shared__ __attribute__((aligned(16))) float s_h[2][H];
+    __shared__ float s_gi[3 * H];
+    __shared__ float s_pro[768];
+
+    float2v w2[3][8];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const float4* row = reinterpret_cast<const float4*>(whh + (int64_t)(g * H + u) * H + 16 * q);
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const float4 v = row[k4];
+            w2[g][2 * k4] = float2v{v.x, v.y};
+            w2[g][2 * k4 + 1] = float2v{v.z, v.w};
+        }
+    }
+    float bias[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) bias[g] = bhh[g * H + u];
+    float h = io.h0[net] ? io.h0[net][(int64_t)b * (io.h0_sb[net] ? io.h0_sb[net] : (int64_t)io.J * H) + (int64_t)j * H + u] : 0.0f;
+
+    // STATIC (one input transform per sequence: computed by the prologue, or gi [B,1,J,3H]): three registers for the whole
+    // scan.  Otherwise gi [B,T,J,3H] streams through a ring of three register slots filled two steps ahead (see
+    // gru_sequence_kernel) — by GLOBAL loads only: a pointer that may also address LDS compiles to flat loads, which
+    // count on lgkmcnt as well, so the wait for the step's ds_reads would wait for the prefetch too.
+    const bool gi_inkernel = STATIC && io.obs != nullptr;
+    if (gi_inkernel) scan_prologue<H, NW>(io, net, b, j, s_pro, s_gi, lane, wave);
+    float ring[3][3];
+    if (STATIC) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const float v = gi_inkernel ? s_gi[g * H + u] : gi[((int64_t)b * io.J + j) * (3 * H) + g * H + u];
+            ring[0][g] = v; ring[1][g] = v; ring[2][g] = v;
+        }
+    } else if (T > 0) {
+        const float* r0 = gi + (((int64_t)b * T) * io.J + j) * (3 * H);
+        const float* r1 = gi + (((int64_t)b * T + (T > 1 ? 1 : 0)) * io.J + j) * (3 * H);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) { ring[0][g] = r0[g * H + u]; ring[1][g] = r1[g * H + u]; }
+    }
+    if (q == 0) s_h[0][u] = h;
+    __syncthreads();
+
+    auto step = [&](auto slot_c, int t) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        constexpr int PRE = (SLOT + 2) % 3;
+        const int buf = t & 1;
+        const float4* hp = reinterpret_cast<const float4*>(&s_h[buf][16 * q]);
+        const float4 h0v = hp[0], h1v = hp[1], h2v = hp[2], h3v = hp[3];
+        if constexpr (!STATIC) {
+            const float* rn = gi + (((int64_t)b * T + (t + 2 < T ? t + 2 : T - 1)) * io.J + j) * (3 * H);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) ring[PRE][g] = rn[g * H + u];
+        }
+        const float2v hv[8] = {float2v{h0v.x, h0v.y}, float2v{h0v.z, h0v.w}, float2v{h1v.x, h1v.y}, float2v{h1v.z, h1v.w},
+                               float2v{h2v.x, h2v.y}, float2v{h2v.z, h2v.w}, float2v{h3v.x, h3v.y}, float2v{h3v.z, h3v.w}};
+        float gh[3];
+        float2v acc[3] = {float2v{0.0f, 0.0f}, float2v{0.0f, 0.0f}, float2v{0.0f, 0.0f}};
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[g] = __builtin_elementwise_fma(w2[g][kk], hv[kk], acc[g]);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) gh[g] = quad_sum(acc[g].x + acc[g].y) + bias[g];
+        const float r = gru_sigmoid(ring[SLOT][0] + gh[0]);
+        const float z = gru_sigmoid(ring[SLOT][1] + gh[1]);
+        const float nn = gru_tanh_folded(ring[SLOT][2] + r * gh[2]);
+        h = (h - nn) * z + nn;
+        if (q == 0) {
+            s_h[buf ^ 1][u] = h;
+            out[(((int64_t)b * T + t) * io.J + j) * H + u] = h;
+        }
+        __syncthreads();
+    };
+    for (int t = 0; t < T; t += 3) {
+        step(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < T) step(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < T) step(std::integral_constant<int, 2>{}, t + 2);
+    }
+}
+
 }  // namespace macjd
 
 extern "C" int macjd_gru_sequence(const macjd_gru_io* io, void* hip_stream) {
@@ -492,7 +620,14 @@ extern "C" int macjd_gru_sequence(const macjd_gru_io* io, void* hip_stream) {
     if (io->B == 0 || io->T == 0) return MACJD_OK;
     const dim3 g((unsigned)(io->B * io->J), (unsigned)io->n_nets);
     hipStream_t s = (hipStream_t)hip_stream;
-    if (io->H == 64) hipLaunchKernelGGL((gru_sequence_kernel<64, 4>), g, dim3(256), 0, s, *io);
+    // H = 64: the unit-split scan; MACJD_GRU_SCAN=ksplit keeps the K-split form (A/B runs, tests compare the two)
+    const char* scan_env = getenv("MACJD_GRU_SCAN");   // read per call: a test switches it inside one process
+    const bool ksplit = scan_env && !strcmp(scan_env, "ksplit");
+    if (io->H == 64 && !ksplit) {
+        if (io->obs || io->reserved) hipLaunchKernelGGL(gru_sequence_units_kernel<true>, g, dim3(256), 0, s, *io);
+        else hipLaunchKernelGGL(gru_sequence_units_kernel<false>, g, dim3(256), 0, s, *io);
+    }
+    else if (io->H == 64) hipLaunchKernelGGL((gru_sequence_kernel<64, 4>), g, dim3(256), 0, s, *io);
     else hipLaunchKernelGGL((gru_sequence_kernel<128, 8>), g, dim3(512), 0, s, *io);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));

@@ -46,7 +46,9 @@ for E, kern in ((4096, "env_step_kernel" if per_env else "env_step_slots_kernel"
 # `bench.py --mode rollout`, dispatches recognised by their grid size
 if not per_env:
     T_STEPS, E0 = 100, 4096
-    B_MANY = 8 * J + 4 + 4 + 4 + 12 + 1 + (R + 4) / T_STEPS
+    # compulsory bytes (bench.py, B_many): actions read + reward / components / terminated written per work item; step
+    # counter, episode index (read) and track (written) once per env
+    B_MANY = 8 * J + 4 + 12 + 1 + (8 + R) / T_STEPS
     rec = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         vals = []

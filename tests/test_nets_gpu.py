@@ -536,12 +536,18 @@ def test_bf16_mixer_error_bound_vs_reference(tag):
                 assert rel <= 2.0 ** -3, (key, k, rel)
 
 
+@pytest.mark.parametrize("scan", ["units", "ksplit"])
 @pytest.mark.parametrize("H", [64, 128])
 @pytest.mark.parametrize("B,T,J", [(1, 1, 1), (3, 7, 2), (32, 100, 3)])
-def test_gru_sequence_kernel(H, B, T, J):
+def test_gru_sequence_kernel(H, B, T, J, scan, monkeypatch):
     """Fused GRU scan (one launch, eval + target weights together) == step-by-step torch.nn.GRUCell
-    arithmetic on the host (the oracle formulation), with and without an initial state."""
+    arithmetic on the host (the oracle formulation), with and without an initial state.  H = 64 has two kernels: the
+    unit-split scan (default) and the K-split one (MACJD_GRU_SCAN=ksplit, also the H = 128 kernel)."""
     from macjd_amd import ops
+    if scan == "ksplit":
+        if H != 64:
+            pytest.skip("H = 128 has the K-split kernel only")
+        monkeypatch.setenv("MACJD_GRU_SCAN", "ksplit")
     rng = np.random.default_rng(H + T)
     gis = [torch.tensor(rng.standard_normal((B, T, J, 3 * H)), dtype=torch.float32) for _ in range(2)]
     ws = [torch.tensor(rng.standard_normal((3 * H, H)) / np.sqrt(H), dtype=torch.float32) for _ in range(2)]
@@ -559,6 +565,13 @@ def test_gru_sequence_kernel(H, B, T, J):
         np.testing.assert_allclose(g_.cpu().numpy(), r_.numpy(), atol=TOL, rtol=0)
     single = ops.gru_sequence(gis[0].to(DEV), ws[0].to(DEV), bs[0].to(DEV))
     assert torch.equal(single, got[0])
+    # one input transform per sequence ([B, 1, J, 3H], static observation) == the same row at every step
+    st = ops.gru_sequence_multi([g[:, :1].contiguous().to(DEV) for g in gis], [w.to(DEV) for w in ws], [b.to(DEV) for b in bs],
+                                [None, h0.to(DEV)], n_steps=T)
+    ref_st = [ops.gru_sequence_reference(gis[0][:, :1].expand(B, T, J, 3 * H), ws[0], bs[0]),
+              ops.gru_sequence_reference(gis[1][:, :1].expand(B, T, J, 3 * H), ws[1], bs[1], h0)]
+    for g_, r_ in zip(st, ref_st):
+        np.testing.assert_allclose(g_.cpu().numpy(), r_.numpy(), atol=TOL, rtol=0)
 
 
 @pytest.mark.parametrize("T,N,B,steps,single,shared", [(12, 40, 8, 7, True, "1"), (100, 48, 32, 4, True, "1"),
@@ -624,8 +637,10 @@ def test_graphed_train_equals_eager_train(T, N, B, steps, single, shared, monkey
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-5, rtol=0, err_msg=k)
 
 
-def test_learner_static_observation_hoist_equals_per_step_evaluation(monkeypatch):
-    """Episodes stored by the batched runner carry ``buffer.obs_static``: the graphed update then evaluates the input
+@pytest.mark.parametrize("actor_in_scan", ["1", "0"])
+def test_learner_static_observation_hoist_equals_per_step_evaluation(actor_in_scan, monkeypatch):
+    """(actor_in_scan: the actor chain of the step-0 rows inside the scan launch's prologue — the default — or as its own
+    launch on the origin stream.)  Episodes stored by the batched runner carry ``buffer.obs_static``: the graphed update then evaluates the input
     transform and the actor chain on the B * J step-0 rows only (the scan reads one input transform per sequence) instead
     of on all B * (T + 1) * J identical rows.  Same kernels on the same row values: statistics and weights after several
     updates equal the per-step evaluation (MACJD_LEARNER_STATIC_OBS=0); a single stored episode of unknown provenance
@@ -637,6 +652,7 @@ def test_learner_static_observation_hoist_equals_per_step_evaluation(monkeypatch
     from macjd_amd.utils.replay_buffer import EpisodeReplayBuffer
     sc, _ = load_scenario("3j4r")
     E, Bsz = 64, 32
+    monkeypatch.setenv("MACJD_ACTOR_IN_SCAN", actor_in_scan)
     def build(hoist):
         monkeypatch.setenv("MACJD_LEARNER_STATIC_OBS", "1" if hoist else "0")
         env = BatchedElectromagneticEnvironment(scenario=sc, batch_envs=E, device=DEV, seed=5)
@@ -654,7 +670,7 @@ def test_learner_static_observation_hoist_equals_per_step_evaluation(monkeypatch
         runner.run(sync_stats=False)
         assert buf.obs_static is True
         learner.enable_graphs(buf, Bsz)
-        assert learner._g_obs_static == hoist
+        assert learner._g_obs_static == hoist and learner._g_actor_in_scan == (actor_in_scan == "1")
         return learner, buf, mac, runner
     la, ba, ma, ra = build(True)
     lb, bb, mb, _ = build(False)
@@ -915,8 +931,9 @@ def test_gru_gates_kernel_vs_torch_cell(N, H):
     np.testing.assert_allclose(ops.gru_gates(gi, gh, h).numpy(), ref.numpy(), atol=TOL, rtol=0)   # host form
 
 
+@pytest.mark.parametrize("scan", ["units", "ksplit"])
 @pytest.mark.parametrize("tag", ["3j4r_h64", "2j2r_h128", "6j8r_h64"])
-def test_gru_scan_with_in_kernel_input_transform_and_actor(tag):
+def test_gru_scan_with_in_kernel_input_transform_and_actor(tag, scan, monkeypatch):
     """Static observation: the scan launch computes each sequence's input transform (fc1 -> ReLU -> W_ih) and actor
     chain itself from the observation row it finds through an index into a [N, T+1, J, S] ring == torch layers on the
     gathered rows followed by the ordinary scan; the Double-DQN launch then reads one actor row per sequence."""
@@ -925,6 +942,10 @@ def test_gru_scan_with_in_kernel_input_transform_and_actor(tag):
     g, d = load(tag)
     args = _gpu_args(d)
     H, A, J, S = d["H"], d["A"], d["J"], d["S"]
+    if scan == "ksplit":
+        if H != 64:
+            pytest.skip("H = 128 has the K-split kernel only")
+        monkeypatch.setenv("MACJD_GRU_SCAN", "ksplit")
     torch.manual_seed(2)
     with quiet():
         agents = [RNNAgent(S, args).to(DEV), RNNAgent(S, args).to(DEV)]
