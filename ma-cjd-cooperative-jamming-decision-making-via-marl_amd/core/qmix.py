@@ -404,9 +404,6 @@ class QMixLearner:
                 p_target = None if (shared or pre_actor is not None) else actor_all(macs[0].agent)
             if pre_actor is not None:      # [B, J, A] per controller, from the scan launch's prologue: [target, eval]
                 p_target, p_eval = (None if shared else pre_actor[0]), pre_actor[1]
-                if not fused_dq:           # the two-launch Double-DQN form wants one row per (b, t, j)
-                    ex = lambda p_: p_.view(B, 1, J, A).expand(B, T1, J, A).reshape(n, A)
-                    p_target, p_eval = (None if p_target is None else ex(p_target)), ex(p_eval)
             eval_q_tot = eval_forward()
             if pre_actor is None:          # only the Double-DQN launches behind the join read it: issued after the eval
                 with torch.no_grad():      # forward, whose autograd chain is the longer part of this stream
@@ -418,6 +415,11 @@ class QMixLearner:
                 origin.wait_stream(ts)                                                          # join
                 for t_ in list(bases) + ([p_target] if p_target is not None else []) + ([p_eval] if pre_actor is not None else []):
                     t_.record_stream(origin)
+                if pre_actor is not None and not fused_dq:
+                    # the two-launch Double-DQN form wants one row per (b, t, j): expanded HERE, behind the join — the
+                    # rows come from the side stream's scan launch
+                    ex = lambda p_: p_.view(B, 1, J, A).expand(B, T1, J, A).reshape(n, A)
+                    p_target, p_eval = (None if p_target is None else ex(p_target)), ex(p_eval)
                 params = [p_eval if shared else p_target, p_eval]
                 target_q_tot = self.target_qmix_net(double_q(bases, params), st["state"], hyper=hyper)   # qmix.py:151
         else:
