@@ -179,6 +179,29 @@ typedef struct macjd_adam_io {
 int macjd_clip_adam_step(const macjd_adam_io* io, void* hip_stream);
 
 /*
+ * Draw of the NEXT update's episodes on the device: idx_out[0..n) = n distinct indices, uniform over [0, *n_stored) —
+ * what the reference's buffer does on the host with np.random.choice(current_size, batch, replace=False)
+ * (utils/replay_buffer.py:89) — as the first n images of a keyed pseudo-random permutation of [0, *n_stored):
+ * an 8-round Feistel network on the ceil(log2 N) bits of an index, cycle-walked back into [0, N), round keys =
+ * Philox4x32-10(counter = *counter, key = seed).  *counter advances by one per draw, so a sequence of draws is a
+ * function of (seed, first counter value) only.  A host-drawn batch needs an index upload between two updates, which
+ * sits on the serial chain of the replayed graphs (~10 us of a ~190 us step); this draw rides at the end of the previous
+ * update's last launch (macjd_clip_adam_step_sample), or stands alone (macjd_sample_episodes: first draw, redraw after
+ * the population changed).  *n_stored < n: idx_out[i] = i mod *n_stored (callers fall back to the host path before).
+ */
+typedef struct macjd_sampler_io {
+    int64_t* idx_out;          /* [n] */
+    int32_t n, reserved;
+    const int32_t* n_stored;   /* device scalar: stored episodes (the population) */
+    int64_t* counter;          /* device scalar: draws made so far */
+    uint64_t seed;
+} macjd_sampler_io;
+
+int macjd_sample_episodes(const macjd_sampler_io* io, void* hip_stream);
+/* macjd_clip_adam_step followed, inside its last launch, by the draw of the next update's episodes (next may be NULL) */
+int macjd_clip_adam_step_sample(const macjd_adam_io* io, const macjd_sampler_io* next, void* hip_stream);
+
+/*
  * Weight and bias gradient of y = x W^T + b over K rows:  dW[M,N] = gout[K,M]^T x inp[K,N],  db[M] = sum_k gout[k,:]
  * (the backward of torch.nn.Linear for its parameters, core/qmix.py:198 loss.backward()).  On this path the outputs
  * are tiny (e.g. [192,128]) and K is 3e3..1e4 rows, so the reduction is split over K: every workgroup computes one

@@ -97,7 +97,8 @@ def make_step(cli, sc, env, dev, rank, world, mode):
     runner = BatchedEpisodeRunner(env, mac, buf, args)
     T = args.episode_limit
     np.random.seed(1234 + rank)  # replay sampling stream of buffer.sample (np.random.choice, like the reference)
-    learner._sample_rng = np.random.default_rng(1234 + rank)   # ... and of the graphed update's own sampler
+    learner._sample_rng = np.random.default_rng(1234 + rank)   # ... and of the graphed update's own samplers
+    learner._sampler_seed_value = 1234 + rank                  # (host draw for explicit / ragged batches, device draw)
     use_graphs = not getattr(cli, "no_graphs", False)
     if mode == "train":
         runner.run(test_mode=False, sync_stats=False)  # untimed pre-fill of the replay buffer

@@ -451,12 +451,12 @@ class QMixLearner:
             self._flatten_grads()
         return loss.detach(), eval_mean.detach(), target_mean.detach()
 
-    def _clip_and_step(self):
+    def _clip_and_step(self, sample_next=None):
         if self._flat_param is not None:   # HIP device: fused clip_grad_norm_ + Adam on the flat vectors
             g = self.optimizer.param_groups[0]
             ops.clip_adam_step(self._flat_param, self._flat_grad, self._flat_exp_avg, self._flat_exp_avg_sq,
                                self._adam_step, self._grad_norm, self._adam_partials, g["lr"], g["betas"], g["eps"],
-                               self.args.grad_norm_clip)
+                               self.args.grad_norm_clip, sample_next=sample_next)
             return self._grad_norm
         grad_norm = torch.nn.utils.clip_grad_norm_(self.params, self.args.grad_norm_clip)  # qmix.py:199
         self.optimizer.step()
@@ -509,6 +509,16 @@ class QMixLearner:
         self._g_scan_from_ring = self._g_obs_static and os.environ.get("MACJD_SCAN_FROM_RING", "1") != "0" \
             and int(buffer.buffers["obs"].shape[-1]) <= 3 * int(self.args.rnn_hidden_dim)
         self._g_idx = torch.zeros(self._g_B, dtype=torch.int64, device=self.device)
+        # The batch of an update whose caller passes no indices is drawn ON THE DEVICE by the previous update's last
+        # launch (ops.sample_episodes: uniform without replacement over the stored episodes, like the reference's
+        # np.random.choice in buffer.sample): no index upload between two replayed updates — that copy and its two
+        # stream-order hops were ~10 us of a ~190 us step.  MACJD_DEVICE_SAMPLER=0: host draw + upload.
+        self._g_dev_sampler = self._flat_param is not None and os.environ.get("MACJD_DEVICE_SAMPLER", "1") != "0"
+        self._g_n_stored = torch.zeros(1, dtype=torch.int32, device=self.device)
+        if getattr(self, "_g_draws", None) is None:   # draws made so far (the sampler's counter; survives a re-capture)
+            self._g_draws = torch.full((1,), int(getattr(self, "_resume_draws", 0)), dtype=torch.int64, device=self.device)
+        self._g_pop_seen = None       # (store_count, current_size) the device-side population scalar / last draw refer to
+        self._g_idx_fresh = False     # _g_idx holds a device draw from the current population that no update has used yet
         self._g_idx_ring = [(torch.zeros(self._g_B, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(8)]
         if buffer.current_size < 1:
             raise RuntimeError("enable_graphs: the replay buffer is empty")
@@ -548,7 +558,7 @@ class QMixLearner:
         with torch.cuda.stream(s):
             for _ in range(max(1, warmup_iters)):
                 body_a()
-                self._clip_and_step()
+                self._clip_and_step()   # (no draw: the warm-up leaves the sampler's counter alone)
         torch.cuda.current_stream(self.device).wait_stream(s)
         with torch.no_grad():
             for p, sp in zip(self.params, snap_p):
@@ -574,11 +584,12 @@ class QMixLearner:
             if st4 is not None and st4.numel() == 4:
                 self._grad_norm = st4[3]
             self._g_stats4 = st4 if (st4 is not None and st4.numel() == 4) else None
+            nxt = (self._g_idx, self._g_n_stored, self._g_draws, self._sampler_seed()) if self._g_dev_sampler else None
             if self._g_single:
-                self._g_out_b = self._clip_and_step()
+                self._g_out_b = self._clip_and_step(sample_next=nxt)
         if not self._g_single:
             with torch.cuda.graph(self._graph_b, pool=self._graph_a.pool(), capture_error_mode="thread_local"):
-                self._g_out_b = self._clip_and_step()
+                self._g_out_b = self._clip_and_step(sample_next=nxt)
         self._g_shared_body = self._body_is_shared()   # baked into the captured launches
         assert self._g_obs_static == (bool(getattr(buffer, "obs_static", False)) and os.environ.get("MACJD_LEARNER_STATIC_OBS", "1") != "0")
         self._graphs_ready = True
@@ -591,17 +602,21 @@ class QMixLearner:
         buf = self._g_buffer if getattr(self, "_graphs_ready", False) else None
         if buf is None:
             raise RuntimeError("call enable_graphs(buffer, batch_size) first")
+        device_draw = False
         if indices is None:
-            # uniform without replacement like the reference's buffer.sample (replay_buffer.py:89), but from the
-            # learner's own numpy Generator: the legacy np.random.choice shuffles the whole population per call
-            # (~90 us for 8192 stored episodes — more host time than the rest of the update's launch), Generator.choice
-            # takes ~4 us.  EpisodeReplayBuffer.sample() keeps the reference's call.
             if buf.current_size < self._g_B:   # fewer stored episodes than a batch: sample what is there, like
                 return self._snap(self.train(buf.sample(self._g_B), None, sync_stats=sync_stats), stats_row)   # buffer.sample does
-            indices = self._sample_rng.choice(buf.current_size, self._g_B, replace=False)
-        indices = np.asarray(indices, dtype=np.int64)
-        if len(indices) != self._g_B or int(buf.episode_lengths[indices].min()) != self._g_T:
-            return self._snap(self.train(buf.sample(len(indices), indices=indices), None, sync_stats=sync_stats), stats_row)
+            device_draw = self._g_dev_sampler and self._population_full_length(buf)
+            if not device_draw:
+                # uniform without replacement like the reference's buffer.sample (replay_buffer.py:89), but from the
+                # learner's own numpy Generator: the legacy np.random.choice shuffles the whole population per call
+                # (~90 us for 8192 stored episodes — more host time than the rest of the update's launch),
+                # Generator.choice takes ~4 us.  EpisodeReplayBuffer.sample() keeps the reference's call.
+                indices = self._sample_rng.choice(buf.current_size, self._g_B, replace=False)
+        if not device_draw:
+            indices = np.asarray(indices, dtype=np.int64)
+            if len(indices) != self._g_B or int(buf.episode_lengths[indices].min()) != self._g_T:
+                return self._snap(self.train(buf.sample(len(indices), indices=indices), None, sync_stats=sync_stats), stats_row)
         if self._g_obs_static and not buf.obs_static:
             raise RuntimeError("an episode with unknown / changing observations was stored after enable_graphs() captured "
                                "the static-observation update: call enable_graphs() again")
@@ -609,16 +624,28 @@ class QMixLearner:
             raise RuntimeError("the agent body (fc1 / GRU / actor) of one controller changed after enable_graphs() captured "
                                "the shared-body update: call enable_graphs() again")
         self.train_step += 1
-        # index upload from a small ring of pinned buffers: a copy from pageable memory makes the host wait for the
-        # stream (it could then never run ahead of the GPU and every node of the next replay would be issued just in
-        # time); a slot is reused only after the copy that read it has completed
-        k = self.train_step % len(self._g_idx_ring)
-        slot, ev = self._g_idx_ring[k]
-        ev.synchronize()
-        slot.numpy()[:] = indices
-        self._g_idx.copy_(slot, non_blocking=True)
-        ev.record()
+        if device_draw:
+            # the previous update's last launch drew this batch already — unless the population changed since (a
+            # rollout stored episodes) or that draw was overwritten by a caller's indices: then one small launch redraws
+            pop = (buf.store_count, buf.current_size)
+            if pop != self._g_pop_seen:
+                self._g_n_stored.fill_(buf.current_size)
+                self._g_pop_seen, self._g_idx_fresh = pop, False
+            if not self._g_idx_fresh:
+                ops.sample_episodes(self._g_idx, self._g_n_stored, self._g_draws, self._sampler_seed())
+        else:
+            # index upload from a small ring of pinned buffers: a copy from pageable memory makes the host wait for the
+            # stream (it could then never run ahead of the GPU and every node of the next replay would be issued just
+            # in time); a slot is reused only after the copy that read it has completed
+            k = self.train_step % len(self._g_idx_ring)
+            slot, ev = self._g_idx_ring[k]
+            ev.synchronize()
+            slot.numpy()[:] = indices
+            self._g_idx.copy_(slot, non_blocking=True)
+            ev.record()
         self._graph_a.replay()
+        # (the replayed update ends with the draw of the next batch from the population the device scalar names)
+        self._g_idx_fresh = self._g_dev_sampler and (buf.store_count, buf.current_size) == self._g_pop_seen
         if not self._g_single:
             self._allreduce_grads()
             self._graph_b.replay()
@@ -628,6 +655,19 @@ class QMixLearner:
             stats_row.copy_(self._g_stats4, non_blocking=True)
             return {"loss": stats_row[0], "grad_norm": stats_row[3], "eval_qtot_avg": stats_row[1], "target_qtot_avg": stats_row[2]}
         return self._snap(self._pack_stats(loss, self._g_out_b, ev, tg, sync_stats), stats_row)
+
+    def _sampler_seed(self):
+        """Key of the device-side episode sampler: the learner's seed, set apart per rank like the host sampler's."""
+        return getattr(self, "_sampler_seed_value", int(getattr(self.args, "seed", 0) or 0))
+
+    def _population_full_length(self, buf):
+        """Every stored episode has the full episode_limit length (what the captured update assumes): checked on the host
+        copy of the lengths, once per change of the buffer's content."""
+        key = (buf.store_count, buf.current_size)
+        if getattr(self, "_g_full_key", None) != key:
+            self._g_full_key = key
+            self._g_full = bool((buf.episode_lengths[:buf.current_size] == self._g_T).all())
+        return self._g_full
 
     @staticmethod
     def _snap(stats, stats_row):

@@ -829,7 +829,46 @@ __global__ void __launch_bounds__(256) adam_sqnorm_kernel(const macjd_adam_io io
     }
 }
 
-__global__ void __launch_bounds__(256) adam_update_kernel(const macjd_adam_io io, const int n_partials) {
+// ---- device-side draw of the next update's episodes (include/macjd_nets.h, macjd_sampler_io) ----
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {   // MurmurHash3 finaliser
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+// one block; every thread reads the counter, thread 0 advances it after the barrier
+__device__ __forceinline__ void sample_episodes_block(const macjd_sampler_io& sp) {
+    const int64_t c = *sp.counter;
+    const int64_t N = (int64_t)*sp.n_stored;
+    __syncthreads();
+    if (threadIdx.x == 0) *sp.counter = c + 1;
+    if (N < 1) return;
+    const Philox4 ka = philox4x32_10((uint32_t)c, (uint32_t)((uint64_t)c >> 32), 0x53414d50u, 0u, (uint32_t)sp.seed, (uint32_t)(sp.seed >> 32));
+    const Philox4 kb = philox4x32_10((uint32_t)c, (uint32_t)((uint64_t)c >> 32), 0x53414d50u, 1u, (uint32_t)sp.seed, (uint32_t)(sp.seed >> 32));
+    const uint32_t key[8] = {ka.v[0], ka.v[1], ka.v[2], ka.v[3], kb.v[0], kb.v[1], kb.v[2], kb.v[3]};
+    int k = 2;                                   // bits of the permuted domain: 2^k >= N
+    while (((int64_t)1 << k) < N) ++k;
+    const int rb = k - k / 2, lb = k / 2;        // right / left half widths (rb >= lb >= 1)
+    const uint32_t rmask = (1u << rb) - 1u, lmask = (1u << lb) - 1u;
+    for (int t = threadIdx.x; t < sp.n; t += blockDim.x) {
+        if (N < sp.n) { sp.idx_out[t] = t % N; continue; }
+        uint32_t x = (uint32_t)t;
+        for (int walk = 0; walk < 64; ++walk) {  // cycle-walking: expected < 2 passes (2^k < 2 N)
+            uint32_t L = x >> rb, R = x & rmask;
+#pragma unroll
+            for (int r = 0; r < 8; r += 2) {
+                L = (L ^ fmix32(R ^ key[r])) & lmask;
+                R = (R ^ fmix32(L ^ key[r + 1])) & rmask;
+            }
+            x = (L << rb) | R;
+            if ((int64_t)x < N) break;
+        }
+        sp.idx_out[t] = ((int64_t)x < N) ? (int64_t)x : (int64_t)(x % (uint32_t)N);
+    }
+}
+
+__global__ void __launch_bounds__(256) sample_episodes_kernel(const macjd_sampler_io sp) { sample_episodes_block(sp); }
+
+template <bool SAMPLE>
+__global__ void __launch_bounds__(256) adam_update_kernel(const macjd_adam_io io, const int n_partials, const macjd_sampler_io next) {
     __shared__ float s_tot;
     if (threadIdx.x < 64) {
         float s = 0.0f;
@@ -858,7 +897,8 @@ __global__ void __launch_bounds__(256) adam_update_kernel(const macjd_adam_io io
         io.param[i] -= step_size * (m / denom);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) io.grad_norm[0] = total_norm;
-    // the step counter is bumped by a trailing single-thread launch (all blocks must have read the old value)
+    // every reader of the current batch's indices ran in an earlier launch of this stream: the next batch is drawn here
+    if (SAMPLE && blockIdx.x == 0) sample_episodes_block(next);
 }
 
 __global__ void __launch_bounds__(256) gather_rows_kernel(const macjd_gather_io io) {
@@ -882,19 +922,38 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const macjd_gather_io 
 
 }  // namespace macjd
 
-extern "C" int macjd_clip_adam_step(const macjd_adam_io* io, void* hip_stream) {
+static int sampler_args_ok(const macjd_sampler_io* sp) {
+    return sp && sp->idx_out && sp->n >= 1 && sp->n_stored && sp->counter;
+}
+
+extern "C" int macjd_sample_episodes(const macjd_sampler_io* io, void* hip_stream) {
+    using namespace macjd;
+    if (!sampler_args_ok(io)) return set_nets_err(MACJD_EINVAL, "macjd_sample_episodes: bad argument");
+    hipLaunchKernelGGL(sample_episodes_kernel, dim3(1), dim3(256), 0, (hipStream_t)hip_stream, *io);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
+    return MACJD_OK;
+}
+
+extern "C" int macjd_clip_adam_step_sample(const macjd_adam_io* io, const macjd_sampler_io* next, void* hip_stream) {
     using namespace macjd;
     if (!io || io->n < 1 || !io->param || !io->grad || !io->exp_avg || !io->exp_avg_sq || !io->step || !io->grad_norm ||
         !io->partials)
         return set_nets_err(MACJD_EINVAL, "macjd_clip_adam_step: bad argument");
+    if (next && !sampler_args_ok(next)) return set_nets_err(MACJD_EINVAL, "macjd_clip_adam_step_sample: bad sampler argument");
     hipStream_t s = (hipStream_t)hip_stream;
     int blocks = (int)((io->n + 255) / 256);
     if (blocks > ADAM_BLOCKS) blocks = ADAM_BLOCKS;
     hipLaunchKernelGGL(adam_sqnorm_kernel, dim3(blocks), dim3(256), 0, s, *io);
-    hipLaunchKernelGGL(adam_update_kernel, dim3(blocks), dim3(256), 0, s, *io, blocks);
+    if (next) hipLaunchKernelGGL(adam_update_kernel<true>, dim3(blocks), dim3(256), 0, s, *io, blocks, *next);
+    else hipLaunchKernelGGL(adam_update_kernel<false>, dim3(blocks), dim3(256), 0, s, *io, blocks, macjd_sampler_io{});
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
     return MACJD_OK;
+}
+
+extern "C" int macjd_clip_adam_step(const macjd_adam_io* io, void* hip_stream) {
+    return macjd_clip_adam_step_sample(io, nullptr, hip_stream);
 }
 
 extern "C" int macjd_gather_rows(const macjd_gather_io* io, void* hip_stream) {

@@ -152,6 +152,9 @@ def save_checkpoint(learner, runner, save_dir, episode, total_steps):
              # positions of the random streams (plain ints: JSON, nothing pickled)
              "runner_ep": int(getattr(runner, "_ep", -1)),
              "sample_rng": learner._sample_rng.bit_generator.state}
+    draws = getattr(learner, "_g_draws", None)
+    if draws is not None:   # the device-side episode sampler's counter (core/qmix.py, enable_graphs)
+        state["sample_draws"] = int(draws.item())
     ep_idx = getattr(runner.env, "episode_index", None)
     if ep_idx is not None:
         state["env_episode"] = int(ep_idx.max().item())
@@ -177,6 +180,7 @@ def load_checkpoint(learner, runner, load_dir):
             runner._ep = int(state["runner_ep"])
         if "sample_rng" in state:
             learner._sample_rng.bit_generator.state = state["sample_rng"]
+        learner._resume_draws = int(state.get("sample_draws", 0))   # applied when enable_graphs creates the counter
         if "env_episode" in state and getattr(runner.env, "episode_index", None) is not None:
             runner.env.episode_index.fill_(int(state["env_episode"]))
     return state
@@ -223,6 +227,7 @@ def run(args):
     if world > 1:
         mac.select_seed = int(args.seed) + 1000 * rank          # every rank explores with its own stream
         learner._sample_rng = np.random.default_rng(int(args.seed) + rank)
+        learner._sampler_seed_value = int(args.seed) + rank
         parallel.broadcast_parameters([mac.agent, learner.eval_qmix_net])
         learner._update_targets()
     batch_envs = int(getattr(args, "batch_envs", 1) or 1)

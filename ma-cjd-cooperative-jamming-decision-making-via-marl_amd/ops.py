@@ -793,16 +793,39 @@ def td_loss(y, tq, reward, terminated, filled, gamma):
 
 # ---------------------------------------------------------------------------------------------
 # Fused clip_grad_norm_ + Adam on flat vectors (reference core/qmix.py:199-200)
-def clip_adam_step(param, grad, exp_avg, exp_avg_sq, step, grad_norm, partials, lr, betas, eps, max_norm):
+def _sampler_io(idx_out, n_stored, counter, seed):
+    assert idx_out.dtype == torch.int64 and idx_out.is_contiguous() and n_stored.dtype == torch.int32 and counter.dtype == torch.int64
+    assert idx_out.is_cuda and n_stored.device == idx_out.device and counter.device == idx_out.device
+    sp = _native.SamplerIO()
+    sp.idx_out, sp.n, sp.n_stored, sp.counter = idx_out.data_ptr(), idx_out.numel(), n_stored.data_ptr(), counter.data_ptr()
+    sp.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    return sp
+
+
+def sample_episodes(idx_out, n_stored, counter, seed):
+    """Device-side draw of ``idx_out.numel()`` distinct episode indices, uniform over [0, n_stored) (the reference's
+    ``np.random.choice(current_size, batch, replace=False)``, utils/replay_buffer.py:89, without the host): a keyed
+    pseudo-random permutation, see include/macjd_nets.h ``macjd_sampler_io``.  ``n_stored`` int32 [1] and ``counter``
+    int64 [1] live on the device; the counter advances by one."""
+    lib = _native.load()
+    sp = _sampler_io(idx_out, n_stored, counter, seed)
+    with torch.cuda.device(idx_out.device):
+        _native.check(lib.macjd_sample_episodes(ctypes.byref(sp), _stream(idx_out)), "macjd_sample_episodes")
+
+
+def clip_adam_step(param, grad, exp_avg, exp_avg_sq, step, grad_norm, partials, lr, betas, eps, max_norm, sample_next=None):
     """In-place update of ``param`` / ``exp_avg`` / ``exp_avg_sq`` / ``step`` (all flat float32 on one HIP
-    device); writes the pre-clip gradient norm into ``grad_norm``."""
+    device); writes the pre-clip gradient norm into ``grad_norm``.  ``sample_next`` = (idx_out, n_stored, counter,
+    seed): the update launch also draws the NEXT update's episodes (``sample_episodes``) when it is done."""
     lib = _native.load()
     io = _native.AdamIO()
     io.n, io.lr, io.beta1, io.beta2, io.eps, io.max_norm = param.numel(), lr, betas[0], betas[1], eps, max_norm
     io.param, io.grad, io.exp_avg, io.exp_avg_sq = param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr()
     io.step, io.grad_norm, io.partials = step.data_ptr(), grad_norm.data_ptr(), partials.data_ptr()
+    sp = _sampler_io(*sample_next) if sample_next is not None else None
     with torch.cuda.device(param.device):
-        _native.check(lib.macjd_clip_adam_step(ctypes.byref(io), _stream(param)), "macjd_clip_adam_step")
+        _native.check(lib.macjd_clip_adam_step_sample(ctypes.byref(io), ctypes.byref(sp) if sp is not None else None,
+                                                      _stream(param)), "macjd_clip_adam_step")
 
 
 def gather_rows_supported(srcs) -> bool:

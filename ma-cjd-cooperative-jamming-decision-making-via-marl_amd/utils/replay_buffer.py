@@ -69,6 +69,7 @@ class EpisodeReplayBuffer:
         self._static_tag = np.full(N, -1, dtype=np.int64)
         self.current_index = 0
         self.current_size = 0
+        self.store_count = 0     # episodes ever stored: lets a consumer notice that the ring's content changed
         self.lock = threading.Lock()
         print(f"Replay Buffer Initialized: Size={self.buffer_size}, Episode Limit={self.episode_limit} ({self.device})")
 
@@ -185,6 +186,7 @@ class EpisodeReplayBuffer:
         else:
             raise ValueError("Attempting to store more episodes than the buffer capacity in a single call.")
         self.current_size = min(self.current_size + inc, self.buffer_size)
+        self.store_count += inc
         return idx
 
     def __len__(self):

@@ -1,6 +1,6 @@
 set -o pipefail
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; TAG=${1:-r02c}
-python -m pytest tests -x -q -m gpu > $OUT/${TAG}_gpu_tests.log 2>&1; tail -1 $OUT/${TAG}_gpu_tests.log
+if [ "$2" != "notests" ]; then python -m pytest tests -x -q -m gpu > $OUT/${TAG}_gpu_tests.log 2>&1; tail -1 $OUT/${TAG}_gpu_tests.log; fi
 cd /tmp && export TMPDIR=/tmp
 ( cd $ROOT && python3 bench.py --no-cpu-baseline --no-other-modes 2>/dev/null | tail -1 > $OUT/${TAG}_bench.json )
 rm -rf $OUT/prof_tl

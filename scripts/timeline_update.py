@@ -53,3 +53,18 @@ for pos, gaps_ in sorted(per_pos.items()):
     med = statistics.median(gaps_)
     if med > 3.0:
         print(f"  #{pos:2d} {med:6.1f} us before {step[pos][2][:60]}")
+
+# update-to-update period: start of one update's first kernel to the start of the next one's (the host-side cost of a
+# step — index upload, graph launch — shows here as the difference between the period and the span)
+firsts = [ev[i][0] for i in starts]
+ends = [ev[[b for b in bumps if b > i][0]][1] for i in starts]
+per = [(b - a) / 1e3 for a, b in zip(firsts[:-1], firsts[1:])]
+gap = [(firsts[k + 1] - ends[k]) / 1e3 for k in range(len(starts) - 1)]
+span = [(e - s) / 1e3 for s, e in zip(firsts, ends)]
+if per:
+    print(f" over {len(per)} consecutive updates: median period {statistics.median(per):.1f} us, median span {statistics.median(span):.1f} us, "
+          f"median gap between an update's last kernel and the next update's first {statistics.median(gap):.1f} us")
+    # what runs in a typical gap
+    k = len(starts) // 2
+    inside = [(s, e, n, q) for s, e, n, q in ev if ends[k] <= s < firsts[k + 1]]
+    print(f" kernels between update {k} and {k + 1}: " + (", ".join(f"{n[:40]} ({(e - s) / 1e3:.1f} us)" for s, e, n, q in inside) or "none"))

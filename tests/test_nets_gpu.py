@@ -1559,3 +1559,133 @@ def test_norm_merged_linear_gradients_equal_autograd(deferred):
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref_out.detach().cpu().numpy(), atol=2e-5, rtol=1e-5)
     for a, r in zip(got, ref):
         np.testing.assert_allclose(a.cpu().numpy(), r.cpu().numpy(), atol=2e-5 * max(1.0, float(r.abs().max())), rtol=1e-4)
+
+
+def _philox4x32_10(c, k):
+    """Philox4x32-10 (Random123) on Python ints: counter c[4], key k[2] -> 4 words."""
+    c, k = list(c), list(k)
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
+        c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & 0xFFFFFFFF, (p0 >> 32) ^ c[3] ^ k[1], p0 & 0xFFFFFFFF]
+        k = [(k[0] + 0x9E3779B9) & 0xFFFFFFFF, (k[1] + 0xBB67AE85) & 0xFFFFFFFF]
+    return c
+
+
+def _sample_episodes_mirror(n, N, counter, seed):
+    """Host restatement of include/macjd_nets.h macjd_sampler_io: first n images of the keyed permutation of [0, N)."""
+    def fmix(h):
+        h ^= h >> 16; h = (h * 0x85ebca6b) & 0xFFFFFFFF; h ^= h >> 13; h = (h * 0xc2b2ae35) & 0xFFFFFFFF; h ^= h >> 16
+        return h
+    ck = (counter & 0xFFFFFFFF, (counter >> 32) & 0xFFFFFFFF)
+    sk = (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    key = _philox4x32_10((ck[0], ck[1], 0x53414d50, 0), sk) + _philox4x32_10((ck[0], ck[1], 0x53414d50, 1), sk)
+    k = 2
+    while (1 << k) < N:
+        k += 1
+    rb, lb = k - k // 2, k // 2
+    rmask, lmask = (1 << rb) - 1, (1 << lb) - 1
+    out = []
+    for t in range(n):
+        x = t
+        while True:
+            L, R = x >> rb, x & rmask
+            for r in range(0, 8, 2):
+                L = (L ^ fmix(R ^ key[r])) & lmask
+                R = (R ^ fmix(L ^ key[r + 1])) & rmask
+            x = (L << rb) | R
+            if x < N:
+                break
+        out.append(x)
+    return out
+
+
+@pytest.mark.parametrize("n,N", [(32, 8192), (32, 4096), (32, 33), (32, 32), (5, 7), (1, 1), (64, 100000)])
+def test_device_episode_sampler(n, N):
+    """The device-side draw of a batch's episodes: equals its host restatement word for word, indices distinct and in
+    range, the counter advances by one per draw, and over many draws every stored episode is picked about equally often
+    (uniform without replacement, like np.random.choice(N, n, replace=False) of the reference's buffer.sample)."""
+    from macjd_amd import ops
+    idx = torch.full((n,), -1, dtype=torch.int64, device=DEV)
+    n_stored = torch.tensor([N], dtype=torch.int32, device=DEV)
+    counter = torch.tensor([5], dtype=torch.int64, device=DEV)
+    seed = 0x1234ABCD5678
+    draws = []
+    for d in range(3):
+        ops.sample_episodes(idx, n_stored, counter, seed)
+        got = idx.cpu().tolist()
+        assert got == _sample_episodes_mirror(n, N, 5 + d, seed), (d, got)
+        assert len(set(got)) == n and min(got) >= 0 and max(got) < N
+        draws.append(got)
+    assert int(counter.item()) == 8 and draws[0] != draws[1] or N == n == 1
+    if N in (33, 4096):
+        reps = 2000 if N == 33 else 3000
+        counts = np.zeros(N)
+        first = np.zeros(N)
+        for _ in range(reps):
+            ops.sample_episodes(idx, n_stored, counter, seed)
+            g = idx.cpu().numpy()
+            counts[g] += 1
+            first[g[0]] += 1
+        exp = reps * n / N                      # inclusion probability n / N per draw
+        sd = np.sqrt(reps * (n / N) * (1 - n / N))
+        assert np.abs(counts - exp).max() < 6 * sd + 1, (counts.min(), counts.max(), exp)
+        assert first.max() < reps / N + 6 * np.sqrt(reps / N) + 1   # a given position of the batch is uniform too
+
+
+def test_graphed_updates_on_device_drawn_batches(monkeypatch):
+    """train_from_buffer() without indices: the batch was drawn by the previous replayed update's last launch (or by the
+    stand-alone draw for the first update and after the population changed).  The indices found in the learner's index
+    tensor before each update, handed to an eager learner, give the same statistics — so the draw is in place before the
+    update that consumes it starts, and a store in between redraws from the new population."""
+    from macjd_amd.core.mac import BasicMAC
+    from macjd_amd.core.qmix import QMixLearner
+    from macjd_amd.utils.replay_buffer import EpisodeReplayBuffer
+    from tests_golden_helpers import synthetic_batch
+    g, d = load("3j4r_h64")
+    T, N, B = 100, 48, 32
+    def build():
+        args = _gpu_args(d, episode_limit=T, buffer_size=N, batch_size=B, target_update_interval=3)
+        with quiet():
+            mac = BasicMAC(d["S"], args)
+            mac.load_state(sd_from(g, "g5_agent0."))
+            learner = QMixLearner(mac, args)
+            buf = EpisodeReplayBuffer(args)
+        learner.eval_qmix_net.load_state_dict(sd_from(g, "g5_mixer0."))
+        learner._update_targets()
+        full = synthetic_batch(np.random.default_rng(9), args, N, T)
+        for k, v in buf.buffers.items():
+            v.copy_(torch.as_tensor(full[k]).to(v.dtype))
+        buf.current_size, buf.current_index = 40, 40      # 40 of the 48 slots count as stored
+        buf.episode_lengths[:] = T
+        return learner, buf
+    eager, buf_e = build()
+    graphed, buf_g = build()
+    graphed.enable_graphs(buf_g, B)
+    assert graphed._g_dev_sampler
+    seen = []
+    for step in range(6):
+        if step == 3:                                      # "a rollout stored 8 more episodes"
+            for b_ in (buf_e, buf_g):
+                b_.current_size, b_.current_index, b_.store_count = 48, 0, b_.store_count + 8
+        # the draw this update consumes: number `step`, except that the draw made at the end of update 2 (from the old
+        # population) is discarded for a fresh one when the population has changed
+        draw_no = step if step < 3 else step + 1
+        want = _sample_episodes_mirror(B, buf_g.current_size, draw_no, graphed._sampler_seed())
+        if step in (0, 3):   # stand-alone draw inside train_from_buffer (first update / population changed)
+            assert not graphed._g_idx_fresh or graphed._g_pop_seen != (buf_g.store_count, buf_g.current_size)
+        else:                # drawn by the previous update's last launch: already in the index tensor
+            assert graphed._g_idx_fresh and graphed._g_idx.cpu().tolist() == want
+        sg = graphed.train_from_buffer()
+        idx = np.array(want)
+        seen.append(idx)
+        assert len(set(want)) == B and idx.max() < buf_g.current_size
+        se = eager.train(buf_e.sample(B, indices=idx), {})
+        for k in se:
+            assert sg[k] == pytest.approx(se[k], rel=1e-4, abs=1e-6), (step, k)
+    assert int(graphed._g_draws.item()) == 8               # six consumed draws, one discarded, one waiting for the next update
+    assert any(i.max() >= 40 for i in seen[3:])            # the enlarged population is being sampled
+    # MACJD_DEVICE_SAMPLER=0 keeps the host draw + upload
+    monkeypatch.setenv("MACJD_DEVICE_SAMPLER", "0")
+    host, buf_h = build()
+    host.enable_graphs(buf_h, B)
+    assert not host._g_dev_sampler and np.isfinite(host.train_from_buffer()["loss"])
