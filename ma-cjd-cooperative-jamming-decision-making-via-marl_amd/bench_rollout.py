@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import contextlib
 import io
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -35,6 +36,7 @@ def _make_step_fn(cli, runner, learner, buf, args, T, mode, use_graphs, tails):
     """The per-step schedule of the benchmark (no device code here: tests drive it with a fake runner)."""
     state = {"graphed_episode": False}
     fused = use_graphs and getattr(runner, "fused_rollout_available", lambda: False)()
+    group = int(getattr(learner, "_g_multi", None)[0]) if (learner is not None and getattr(learner, "_g_multi", None)) else 1
 
     def step_fn(i):
         # Episodes are aligned to the regions the caller times: the warm-up steps are their own run of episodes and
@@ -63,7 +65,15 @@ def _make_step_fn(cli, runner, learner, buf, args, T, mode, use_graphs, tails):
         if t == T - 1:
             runner.end_episodes()
         if mode == "train":
-            if use_graphs:
+            if use_graphs and group > 1:
+                # one update per env step, issued in groups: the K updates of steps j-K+1 .. j replay ONE graph after
+                # step j (the reference trains after the episode, main.py:212-216; the env steps of the whole episode
+                # batch were launched at t = 0 anyway); the region's remainder goes one by one
+                state["owed"] = state.get("owed", 0) + 1
+                if state["owed"] == group or j == region - 1:
+                    learner.train_from_buffer_many(state["owed"])
+                    state["owed"] = 0
+            elif use_graphs:
                 learner.train_from_buffer(sync_stats=False)
             else:
                 learner.train(buf.sample(args.batch_size), None, sync_stats=False)
@@ -103,7 +113,7 @@ def make_step(cli, sc, env, dev, rank, world, mode):
     if mode == "train":
         runner.run(test_mode=False, sync_stats=False)  # untimed pre-fill of the replay buffer
         if use_graphs:
-            learner.enable_graphs(buf, args.batch_size)
+            learner.enable_graphs(buf, args.batch_size, updates_per_graph=int(os.environ.get("MACJD_UPDATES_PER_GRAPH", "4")))
     tails = set()
     fused_rollout = use_graphs and runner.fused_rollout_available()
     if use_graphs and not fused_rollout:
@@ -116,7 +126,9 @@ def make_step(cli, sc, env, dev, rank, world, mode):
     step_fn = _make_step_fn(cli, runner, learner if mode == "train" else None, buf, args, T, mode, use_graphs, tails)
 
     extra = {"hidden": cli.hidden, "train_batch_episodes": args.batch_size if mode == "train" else 0,
-             "train_calls_per_step": 1 if mode == "train" else 0, "hip_graphs": bool(use_graphs), "gemm_tuning": bool(gemm_tuning),
+             "train_calls_per_step": 1 if mode == "train" else 0,
+             "updates_per_graph": (learner._g_multi[0] if (mode == "train" and use_graphs and learner._g_multi) else 1),
+             "hip_graphs": bool(use_graphs), "gemm_tuning": bool(gemm_tuning),
              "replay_capacity_episodes": args.buffer_size,
              "rollout": "fused: agent-episode launch + many-step env launch per episode batch" if fused_rollout else
                         ("HIP graph of the step-by-step rollout" if use_graphs else "eager step-by-step")}

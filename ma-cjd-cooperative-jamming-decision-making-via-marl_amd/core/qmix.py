@@ -490,7 +490,7 @@ class QMixLearner:
         return getattr(self, "_grad_norm", None)
 
     # ------------------------------------------------------------------ HIP-graph path
-    def enable_graphs(self, buffer, batch_size, warmup_iters=3, force_two_graphs=False):
+    def enable_graphs(self, buffer, batch_size, warmup_iters=3, force_two_graphs=False, updates_per_graph=None):
         """Capture the update as two HIP graphs around the (eager) gradient all-reduce (ONE graph holding both halves
         when there is a single process, i.e. nothing to all-reduce):
           graph A  gather the sampled episodes from the device replay (static index tensor) + both
@@ -590,6 +590,21 @@ class QMixLearner:
         if not self._g_single:
             with torch.cuda.graph(self._graph_b, pool=self._graph_a.pool(), capture_error_mode="thread_local"):
                 self._g_out_b = self._clip_and_step(sample_next=nxt)
+        # K consecutive updates as ONE graph (train_from_buffer_many): between two replayed graphs the stream pays a
+        # launch-to-launch hand-over (~20 us here) that an edge inside a graph does not.  Needs the device-side draw (every
+        # update's batch comes from the previous update's last launch) and a single process (no all-reduce in between).
+        K = int(updates_per_graph if updates_per_graph is not None else os.environ.get("MACJD_UPDATES_PER_GRAPH", "1"))
+        self._g_multi = None
+        if K > 1 and self._g_single and self._g_dev_sampler and fused and self._g_stats4 is not None:
+            gm, rows, single_norm = torch.cuda.CUDAGraph(), [], self._grad_norm
+            with torch.cuda.graph(gm, pool=self._graph_a.pool(), capture_error_mode="thread_local"):
+                for _ in range(K):
+                    body_a()
+                    rows.append(self._last_stats4)          # this update's (loss, mean Q_tot, mean target, grad norm)
+                    self._grad_norm = rows[-1][3]
+                    self._clip_and_step(sample_next=nxt)
+            self._grad_norm = single_norm
+            self._g_multi = (K, gm, rows)
         self._g_shared_body = self._body_is_shared()   # baked into the captured launches
         assert self._g_obs_static == (bool(getattr(buffer, "obs_static", False)) and os.environ.get("MACJD_LEARNER_STATIC_OBS", "1") != "0")
         self._graphs_ready = True
@@ -625,14 +640,7 @@ class QMixLearner:
                                "the shared-body update: call enable_graphs() again")
         self.train_step += 1
         if device_draw:
-            # the previous update's last launch drew this batch already — unless the population changed since (a
-            # rollout stored episodes) or that draw was overwritten by a caller's indices: then one small launch redraws
-            pop = (buf.store_count, buf.current_size)
-            if pop != self._g_pop_seen:
-                self._g_n_stored.fill_(buf.current_size)
-                self._g_pop_seen, self._g_idx_fresh = pop, False
-            if not self._g_idx_fresh:
-                ops.sample_episodes(self._g_idx, self._g_n_stored, self._g_draws, self._sampler_seed())
+            self._device_draw_ready(buf)
         else:
             # index upload from a small ring of pinned buffers: a copy from pageable memory makes the host wait for the
             # stream (it could then never run ahead of the GPU and every node of the next replay would be issued just
@@ -655,6 +663,46 @@ class QMixLearner:
             stats_row.copy_(self._g_stats4, non_blocking=True)
             return {"loss": stats_row[0], "grad_norm": stats_row[3], "eval_qtot_avg": stats_row[1], "target_qtot_avg": stats_row[2]}
         return self._snap(self._pack_stats(loss, self._g_out_b, ev, tg, sync_stats), stats_row)
+
+    def _device_draw_ready(self, buf):
+        """The previous update's last launch drew the next batch already — unless the population changed since (a rollout
+        stored episodes) or that draw was overwritten by a caller's indices: then one small launch redraws."""
+        pop = (buf.store_count, buf.current_size)
+        if pop != self._g_pop_seen:
+            self._g_n_stored.fill_(buf.current_size)
+            self._g_pop_seen, self._g_idx_fresh = pop, False
+        if not self._g_idx_fresh:
+            ops.sample_episodes(self._g_idx, self._g_n_stored, self._g_draws, self._sampler_seed())
+
+    def train_from_buffer_many(self, n):
+        """``n`` consecutive updates on device-drawn batches, the same sequence of updates as ``n`` calls of
+        ``train_from_buffer()`` (same draws, same target syncs): groups of K = updates_per_graph updates replay ONE graph
+        where nothing has to happen between them (no target sync due inside the group), the rest goes one by one.
+        Returns the updates' statistics as float32 [4] device tensors (loss, eval_qtot_avg, target_qtot_avg, grad_norm);
+        the tensors of a replayed group are static outputs that the next replay of the group overwrites."""
+        buf = self._g_buffer if getattr(self, "_graphs_ready", False) else None
+        if buf is None:
+            raise RuntimeError("call enable_graphs(buffer, batch_size) first")
+        out, done = [], 0
+        while done < n:
+            m = self._g_multi
+            until_sync = self.args.target_update_interval - (self.train_step - self.last_target_update_step)
+            if (m is not None and n - done >= m[0] and until_sync >= m[0] and buf.current_size >= self._g_B
+                    and self._population_full_length(buf) and (not self._g_obs_static or buf.obs_static)
+                    and (not self._g_shared_body or self._body_is_shared())):
+                self._device_draw_ready(buf)
+                self.train_step += m[0]
+                m[1].replay()
+                self._g_idx_fresh = (buf.store_count, buf.current_size) == self._g_pop_seen
+                self._after_step()
+                out += m[2]
+                done += m[0]
+            else:
+                row = torch.empty(4, dtype=torch.float32, device=self.device)
+                self.train_from_buffer(sync_stats=False, stats_row=row)
+                out.append(row)
+                done += 1
+        return out
 
     def _sampler_seed(self):
         """Key of the device-side episode sampler: the learner's seed, set apart per rank like the host sampler's."""

@@ -263,10 +263,13 @@ __device__ __forceinline__ float gru_tanh(float x) {
 
 // Prologue of the scan kernels for a static observation (macjd_gru_io.obs); results: s_gi [3H] in LDS and, when asked,
 // io.p_out.  All NW waves of the workgroup take part; ends with a barrier.
+// The two halves are independent given the observation row, so a launch that wants both runs them in DIFFERENT
+// workgroups (blockIdx.z = 0: input transform + scan, blockIdx.z = 1: actor chain only): the actor's three mat-vecs
+// (~9 us) leave the scan's critical path.
 template <int H, int NW>
 __device__ __forceinline__ void scan_prologue(const macjd_gru_io& io, const int net, const int b, const int j,
                                               float* __restrict__ s_pro, float* __restrict__ s_gi, const int lane,
-                                              const int wave) {
+                                              const int wave, const bool want_gi, const bool want_actor) {
     // Prologue for a static observation: this sequence's ONE observation row x -> gi = W_ih ReLU(fc1 x + b) + b_ih
     // and, when asked, the actor chain sigmoid(L3 ReLU(L2 ReLU(L1 x))).  Small mat-vecs on the VALU: an output is a
     // wave-wide dot product (lanes split k: every weight row is read as coalesced 256-B pieces from L2), outputs are
@@ -323,10 +326,12 @@ __device__ __forceinline__ void scan_prologue(const macjd_gru_io& io, const int 
         else if (nch == 2) body(std::integral_constant<int, 2>{});
         else body(std::integral_constant<int, 4>{});
     };
-    matvec(io.fc1_w[net], io.fc1_b[net], xs, S, H, [&](int o, float v) { v1[o] = fmaxf(v, 0.0f); });
-    __syncthreads();
-    matvec(io.w_ih[net], io.b_ih[net], v1, H, 3 * H, [&](int o, float v) { s_gi[o] = v; });
-    if (io.p_out[net]) {
+    if (want_gi) {
+        matvec(io.fc1_w[net], io.fc1_b[net], xs, S, H, [&](int o, float v) { v1[o] = fmaxf(v, 0.0f); });
+        __syncthreads();
+        matvec(io.w_ih[net], io.b_ih[net], v1, H, 3 * H, [&](int o, float v) { s_gi[o] = v; });
+    }
+    if (want_actor && io.p_out[net]) {
         const int Ah = io.Ah, A = io.A;
         __syncthreads();    // v1 is read by the W_ih product above: done before it is overwritten
         matvec(io.act_w[net][0], io.act_b[net][0], xs, S, Ah, [&](int o, float v) { v1[o] = fmaxf(v, 0.0f); });
@@ -357,6 +362,10 @@ __global__ void __launch_bounds__(64 * NW) gru_sequence_kernel(const macjd_gru_i
     __shared__ float s_part[2][NW][3][H];
     __shared__ float s_gi[3 * H];   // in-kernel input transform (static observation), see macjd_gru_io.obs
     __shared__ float s_pro[768];    // prologue scratch: observation row + two hidden vectors
+    if (blockIdx.z == 1) {   // actor-only workgroup of a launch that split the prologue
+        scan_prologue<H, NW>(io, net, b, j, s_pro, s_gi, lane, wave, false, true);
+        return;
+    }
 
     // weights of this wave's K-slice, resident for the whole sequence
     float w[3][U][KW];
@@ -386,7 +395,7 @@ __global__ void __launch_bounds__(64 * NW) gru_sequence_kernel(const macjd_gru_i
     // io.reserved != 0 ("gi_static"): gi is [B, 1, J, 3H], the same input transform at every step (static observation)
     const bool gi_inkernel = io.obs != nullptr;
     const bool gi_static = io.reserved != 0 || gi_inkernel;
-    if (gi_inkernel) scan_prologue<H, NW>(io, net, b, j, s_pro, s_gi, lane, wave);
+    if (gi_inkernel) scan_prologue<H, NW>(io, net, b, j, s_pro, s_gi, lane, wave, true, gridDim.z == 1);
     auto gi_row = [&](int t) -> const float* {
         return gi_inkernel ? (const float*)s_gi
                            : gi_static ? gi + ((int64_t)b * io.J + j) * (3 * H)
@@ -516,6 +525,10 @@ __global__ void __launch_bounds__(256) gru_sequence_units_kernel(const macjd_gru
     __shared__ __attribute__((aligned(16))) float s_h[2][H];
     __shared__ float s_gi[3 * H];
     __shared__ float s_pro[768];
+    if (STATIC && blockIdx.z == 1) {   // actor-only workgroup of a launch that split the prologue
+        scan_prologue<H, NW>(io, net, b, j, s_pro, s_gi, lane, wave, false, true);
+        return;
+    }
 
     float2v w2[3][8];
 #pragma unroll
@@ -538,7 +551,7 @@ __global__ void __launch_bounds__(256) gru_sequence_units_kernel(const macjd_gru
     // gru_sequence_kernel) — by GLOBAL loads only: a pointer that may also address LDS compiles to flat loads, which
     // count on lgkmcnt as well, so the wait for the step's ds_reads would wait for the prefetch too.
     const bool gi_inkernel = STATIC && io.obs != nullptr;
-    if (gi_inkernel) scan_prologue<H, NW>(io, net, b, j, s_pro, s_gi, lane, wave);
+    if (gi_inkernel) scan_prologue<H, NW>(io, net, b, j, s_pro, s_gi, lane, wave, true, gridDim.z == 1);
     float ring[3][3];
     if (STATIC) {
 #pragma unroll
@@ -618,7 +631,9 @@ extern "C" int macjd_gru_sequence(const macjd_gru_io* io, void* hip_stream) {
                     return set_nets_err(MACJD_EINVAL, "macjd_gru_sequence: in-kernel actor needs its three layers");
         }
     if (io->B == 0 || io->T == 0) return MACJD_OK;
-    const dim3 g((unsigned)(io->B * io->J), (unsigned)io->n_nets);
+    // with an in-kernel actor chain: a second layer of workgroups (blockIdx.z = 1) computes it beside the scan
+    const bool actor = io->obs && (io->p_out[0] || (io->n_nets > 1 && io->p_out[1]));
+    const dim3 g((unsigned)(io->B * io->J), (unsigned)io->n_nets, actor ? 2u : 1u);
     hipStream_t s = (hipStream_t)hip_stream;
     // H = 64: the unit-split scan; MACJD_GRU_SCAN=ksplit keeps the K-split form (A/B runs, tests compare the two)
     const char* scan_env = getenv("MACJD_GRU_SCAN");   // read per call: a test switches it inside one process

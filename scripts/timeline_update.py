@@ -68,3 +68,13 @@ if per:
     k = len(starts) // 2
     inside = [(s, e, n, q) for s, e, n, q in ev if ends[k] <= s < firsts[k + 1]]
     print(f" kernels between update {k} and {k + 1}: " + (", ".join(f"{n[:40]} ({(e - s) / 1e3:.1f} us)" for s, e, n, q in inside) or "none"))
+
+# raw window: every kernel from the end of one update's last launch to the end of the next one's (a branch that starts
+# before the gather — the scan — is cut off by the per-update view above)
+if len(starts) > 4:
+    k = len(starts) // 2 + 1
+    w0, w1 = ends[k - 1], ends[k]
+    print(f" raw window of update {k} (t = 0 at the previous update's last kernel end):")
+    for s_, e_, n_, q_ in ev:
+        if w0 - 2000 <= s_ <= w1:
+            print(f"  {(s_ - w0) / 1e3:7.1f} {(e_ - s_) / 1e3:6.1f}  q{q_}  {n_[:70]}")

@@ -1689,3 +1689,59 @@ def test_graphed_updates_on_device_drawn_batches(monkeypatch):
     host, buf_h = build()
     host.enable_graphs(buf_h, B)
     assert not host._g_dev_sampler and np.isfinite(host.train_from_buffer()["loss"])
+
+
+def test_updates_grouped_into_one_graph_equal_single_updates():
+    """train_from_buffer_many(n): groups of K updates replayed as ONE graph (each update's batch drawn on the device by
+    the update before it) where no target sync falls inside the group, single replays otherwise == n calls of
+    train_from_buffer(): same draws, same statistics per update, same weights, same target syncs."""
+    from macjd_amd.core.mac import BasicMAC
+    from macjd_amd.core.qmix import QMixLearner
+    from macjd_amd.utils.replay_buffer import EpisodeReplayBuffer
+    from tests_golden_helpers import synthetic_batch
+    g, d = load("3j4r_h64")
+    T, N, B, K, n = 100, 48, 32, 2, 7
+    def build(k):
+        args = _gpu_args(d, episode_limit=T, buffer_size=N, batch_size=B, target_update_interval=5, lr=1e-3)
+        with quiet():
+            mac = BasicMAC(d["S"], args)
+            mac.load_state(sd_from(g, "g5_agent0."))
+            learner = QMixLearner(mac, args)
+            buf = EpisodeReplayBuffer(args)
+        learner.eval_qmix_net.load_state_dict(sd_from(g, "g5_mixer0."))
+        learner._update_targets()
+        full = synthetic_batch(np.random.default_rng(9), args, N, T)
+        for kk, v in buf.buffers.items():
+            v.copy_(torch.as_tensor(full[kk]).to(v.dtype))
+        buf.current_size, buf.current_index = N, 0
+        buf.episode_lengths[:] = T
+        learner.enable_graphs(buf, B, updates_per_graph=k)
+        return mac, learner
+    mac_1, one = build(1)
+    mac_k, many = build(K)
+    assert one._g_multi is None and many._g_multi[0] == K
+    ref = torch.zeros(n, 4, device=DEV)
+    for i in range(n):
+        one.train_from_buffer(sync_stats=False, stats_row=ref[i])
+    got = torch.stack([r.clone() for r in many.train_from_buffer_many(n)]) if False else None
+    # (the rows of a replayed group are static tensors that the next replay of the group overwrites: snapshot per call)
+    many2_rows = []
+    mac_k2, many2 = mac_k, many
+    done = 0
+    for chunk in (2, 2, 1, 2):     # the grouping train_from_buffer_many(7) itself chooses, spelled out to snapshot the rows
+        many2_rows += [r.clone() for r in many2.train_from_buffer_many(chunk)]
+        done += chunk
+    got = torch.stack(many2_rows)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    assert many.train_step == one.train_step == n and many.last_target_update_step == one.last_target_update_step == 5
+    assert int(many._g_draws.item()) == int(one._g_draws.item()) == n + 1
+    for (k_, a), b in zip(mac_1.agent.state_dict().items(), mac_k.agent.state_dict().values()):
+        assert torch.equal(a, b), k_
+    for (k_, a), b in zip(one.target_qmix_net.state_dict().items(), many.target_qmix_net.state_dict().values()):
+        assert torch.equal(a, b), k_
+    # one call does the same split on its own
+    mac_j, joint = build(K)
+    joint.train_from_buffer_many(n)
+    assert joint.train_step == n and joint.last_target_update_step == 5
+    for (k_, a), b in zip(mac_1.agent.state_dict().items(), mac_j.agent.state_dict().values()):
+        assert torch.equal(a, b), k_
