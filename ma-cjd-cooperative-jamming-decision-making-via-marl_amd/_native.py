@@ -21,7 +21,7 @@ STEP_SLOT_KERNEL = 4
 
 EXPORTS = [
     "macjd_abi_version", "macjd_last_error", "macjd_device_count",
-    "macjd_scenario_create", "macjd_scenario_destroy", "macjd_scenario_dims",
+    "macjd_scenario_create", "macjd_scenario_destroy", "macjd_scenario_dims", "macjd_scenario_is_regular",
     "macjd_env_reset", "macjd_env_step", "macjd_env_step_timed",
     "macjd_qhead_select", "macjd_gru_sequence", "macjd_mixer_tail_forward", "macjd_mixer_tail_backward",
     "macjd_mlp_forward", "macjd_mlp_forward_pair", "macjd_td_loss", "macjd_clip_adam_step", "macjd_clip_adam_step_sample", "macjd_sample_episodes", "macjd_gather_rows",
@@ -292,6 +292,8 @@ def load() -> ctypes.CDLL:
     lib.macjd_scenario_create.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
     lib.macjd_scenario_destroy.restype = None
     lib.macjd_scenario_destroy.argtypes = [ctypes.c_void_p]
+    lib.macjd_scenario_is_regular.restype = ctypes.c_int
+    lib.macjd_scenario_is_regular.argtypes = [ctypes.c_void_p]
     lib.macjd_scenario_dims.restype = ctypes.c_int
     lib.macjd_scenario_dims.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int32)] * 3
     lib.macjd_env_reset.restype = ctypes.c_int

@@ -24,6 +24,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <type_traits>
 
@@ -44,7 +45,17 @@ struct DevTables {
     double pmin[MAXJ], pmax[MAXJ], gj[MAXJ];
     double denom[MAXJ * MAXR];   // packed [j*R + r]; negative = jammer sits on the radar (ignored)
     uint8_t flags[MAXJ * MAXR];  // packed [j*R + r]
+    // ---- derived ON THE DEVICE when the scenario is created (scenario_derive_kernel, with the very device functions the
+    // step kernels divide with), read by the REGULAR production variant (see env_step_kernel, REG) ----
+    int32_t regular, pad2;       // host verdict: every table value in the range where the short division is IEEE division
+    double rPn[MAXR];            // refined reciprocal of Pn
+    double range_fd[MAXJ], r_range[MAXJ];      // (double)(float)(pmax - pmin) and its refined reciprocal
+    double dsel[MAXJ * MAXR], rsel[MAXJ * MAXR];   // divisor of the received-power quotient as the step uses it (1.0 where
+                                                   // it does not divide; the float32-rounded value where the division is
+                                                   // float32) and its refined reciprocal
+    uint8_t rflags[MAXJ * MAXR]; // flags | JR_RECORDABLE (denom >= 0) | JR_LIVE (denom > 1e-18)
 };
+constexpr uint8_t JR_RECORDABLE = 0x40, JR_LIVE = 0x80;
 
 static thread_local char g_err[512] = "";
 int set_err(int code, const char* fmt, const char* a) {
@@ -105,6 +116,22 @@ __device__ __forceinline__ void det_prob_batch(const double* snr, double* pd, co
         p = (B[i] < -700.0) ? 0.0 : p;
         pd[i] = k.degenerate ? 0.0 : p;
     }
+}
+// REGULAR scenarios (host-checked, see macjd_scenario_create): denB > 0 and not degenerate, every SNR the step can form is
+// finite, >= +0 and < 1e100, and B >= (10 c1 - A) / denB >= -700 for every SNR >= 0 — so max(snr, 0), the 1e300 cap and
+// the B < -700 / degenerate selects of the general form never act; B > 700 needs no select at all: exp(-B) < 2^-53
+// there (0 below -745), 1 + exp(-B) rounds to 1.0 and the quotient is exactly the reference's 1.0.
+template <int N>
+__device__ __forceinline__ void det_prob_batch_regular(const double* snr, double* pd, const PdConsts& k) {
+    double den[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double Z = snr[i] + k.c1;
+        const double B = div_by_refined(10.0 * Z - k.A, k.denB, k.r_denB);
+        den[i] = 1.0 + exp(-B);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) pd[i] = div_by_refined(1.0, den[i], rcp_refined(den[i]));
 }
 __device__ __forceinline__ double det_prob(double snr, const PdConsts& k) {
     double p;
@@ -176,26 +203,38 @@ struct FastStepIO {
 // sizes the kernel is VALU-issue bound (PMC: ~1670 VALU instructions per 64-env iteration, VALU busy 73 % of the
 // kernel); the run-time mode tests cost ~50 uniform branches and, through the extra live pointers, ~400 SGPR spill
 // instructions (v_writelane / v_readlane) per iteration.
-template <int JT, int RT, bool PE, bool FAST, class IO>
+// REG = FAST on the shared tables of a REGULAR scenario (DevTables.regular, decided by macjd_scenario_create): every
+// division whose divisor is a table value — the received-power quotient (float64 or float32, chosen per (jammer, radar)
+// pair), the false-target SNR, the power normalisation — multiplies by the divisor's refined reciprocal from the
+// tables (3 instead of 13 / 10 instructions; a float32 quotient is the float64 one rounded once more, which is exact for
+// a quotient of two float32 values: 53 >= 2 * 24 + 2 bits), the radars' SNR division drops the scaling wrapper, and
+// the guards that a regular scenario can never trigger (non-positive or tiny noise power, SNR < 0, the probability
+// formula's saturation selects) are not evaluated.  Same results bit for bit (tests: lane kernel vs (env x slot) kernel,
+// which keeps IEEE division and every guard, and both vs the oracle); 1285 -> ~1050 VALU instructions per env-step at 3j/4r.
+template <int JT, int RT, bool PE, bool FAST, class IO, bool REG = false>
 __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restrict__ tb, const IO io) {
+    static_assert(!REG || (FAST && !PE && JT && RT), "REG: production variant on shared tables, compiled sizes");
     constexpr int NJ = JT ? JT : MAXJ;
     constexpr int NR = RT ? RT : MAXR;
     const int J = JT ? JT : tb->J;
     const int R = RT ? RT : tb->R;
 
     // ---- LDS staging of the tables gathered by per-lane target index (shared-table variant) ----
-    __shared__ double s_denom[PE ? 1 : NJ * NR];
+    __shared__ double s_denom[PE ? 1 : NJ * NR];   // REG: the divisor as used (DevTables.dsel)
+    __shared__ double s_rsel[REG ? NJ * NR : 1], s_rPn[REG ? NR : 1];
     __shared__ double s_D[PE ? 1 : NR], s_Pn[PE ? 1 : NR], s_gr[PE ? 1 : NR];
     __shared__ uint8_t s_flags[PE ? 1 : NJ * NR];
     if (!PE) {
         for (int i = threadIdx.x; i < J * R; i += blockDim.x) {
-            s_denom[i] = tb->denom[i];
-            s_flags[i] = tb->flags[i];
+            s_denom[i] = REG ? tb->dsel[i] : tb->denom[i];
+            s_flags[i] = REG ? tb->rflags[i] : tb->flags[i];
+            if (REG) s_rsel[i] = tb->rsel[i];
         }
         for (int i = threadIdx.x; i < R; i += blockDim.x) {
             s_D[i] = tb->D[i];
             s_Pn[i] = tb->Pn[i];
             s_gr[i] = tb->gr[i];
+            if (REG) s_rPn[i] = tb->rPn[i];
         }
         __syncthreads();
     }
@@ -346,7 +385,11 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
                 Pc = Pc < 0.0f ? 0.0f : (Pc > 1.0f ? 1.0f : Pc);  // np.clip, NaN propagates
                 actual_f = (float)pmin + Pc * (float)power_range;
                 actual_d = (double)actual_f;
-                norm = (power_range > 1e-6) ? (double)((actual_f - (float)pmin) / (float)power_range) : 0.0;
+                if (REG)
+                    norm = (power_range > 1e-6) ? (double)(float)div_by_refined((double)(actual_f - (float)pmin), tb->range_fd[j],
+                                                                                tb->r_range[j]) : 0.0;
+                else
+                    norm = (power_range > 1e-6) ? (double)((actual_f - (float)pmin) / (float)power_range) : 0.0;
             } else {
                 double Pc = io.P64 ? io.P64[e * io.P_se + (int64_t)j * io.P_sx]
                                    : (double)at(io.P32, e, io.P_se, j, io.P_sx, act_extra);
@@ -358,9 +401,18 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
 
             // ---- received jamming power, environment.py:280-302, jammer.py:56-98 ----
             const double denom = g_denom(j, target);
-            const bool recorded = is_jamming && (actual_d > 0.0) && (denom >= 0.0);
+            const bool recorded = REG ? (is_jamming && (actual_d > 0.0) && (g_flags(j, target) & JR_RECORDABLE))
+                                      : (is_jamming && (actual_d > 0.0) && (denom >= 0.0));
             double prj = 0.0;
-            if (PRE) {
+            if (REG) {
+                // `denom` is the divisor as the reference uses it here (1.0 where it does not divide)
+                const uint8_t fl = g_flags(j, target);
+                const bool live = recorded && (fl & JR_LIVE);
+                const float num = (actual_f * (float)t_gj(j)) * (float)g_gr(j, target);
+                const double q64 = div_by_refined((double)num, denom, s_rsel[j * R + target]);
+                const double q = (fl & MACJD_JR_WEAK_DENOM) ? (double)(float)q64 : q64;
+                prj = (live && q > 0.0) ? q : 0.0;  // Python max(0.0, x)
+            } else if (PRE) {
                 // branch-free: the quotient is evaluated on a harmless divisor where the reference does not divide
                 const bool live = recorded && denom > 1e-18;
                 const double dsafe = live ? denom : 1.0;
@@ -396,7 +448,10 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
             dec_tgt[j] = is_dec ? target : -1;
 
             // ---- deception: SNR of the false target, environment.py:410-422 ----
-            if (PRE) {
+            if (REG) {
+                const double snr_f = div_by_refined(g_D(j, target) * prj, g_Pn(j, target), s_rPn[target]);
+                snr_all[NR + j] = (is_dec && snr_f > 0.0) ? snr_f : 0.0;
+            } else if (PRE) {
                 const double Pn_t = g_Pn(j, target);
                 const bool live = is_dec && Pn_t > 1e-18;
                 const double snr_f = (g_D(j, target) * prj) / (live ? Pn_t : 1.0);
@@ -424,7 +479,10 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
             if (!RT && r >= R) break;
             const double Pn = t_Pn(r);
             const double den = t_D(r) * supp[r] + Pn;                       // :331
-            if (PRE) {
+            if (REG) {                                                       // den >= Pn > 1e-18
+                snr_w[r] = div_by_refined(t_GaPs(r), den, rcp_refined(den));
+                snr_all[r] = snr_w[r];
+            } else if (PRE) {
                 const bool live = den > 1e-18;
                 const double q = t_GaPs(r) / (live ? den : 1.0);
                 snr_w[r] = live ? q : 0.0;                                   // :332
@@ -433,7 +491,8 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
                 snr_w[r] = (den > 1e-18) ? t_GaPs(r) / den : 0.0;            // :332
             }
         }
-        if (PRE) det_prob_batch<NP>(snr_all, pd_all, pdk);                   // :337, :425
+        if (REG) det_prob_batch_regular<NP>(snr_all, pd_all, pdk);           // :337, :425
+        else if (PRE) det_prob_batch<NP>(snr_all, pd_all, pdk);
 
         // ---- deception: Monte-Carlo detection of the false targets in jammer order, environment.py:425-447 ----
         if (PRE) {
@@ -485,7 +544,7 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             if (!RT && r >= R) break;
-            const double snr_rep = (snr_w[r] > 0.0) ? snr_w[r] : 0.0;         // :333
+            const double snr_rep = (REG || snr_w[r] > 0.0) ? snr_w[r] : 0.0;  // :333 (regular: never negative)
             if (last_t) at(io.track, e, io.k_se, r, io.k_sx) = (track_bits >> r) & 1u;
             if (io.pd) at(io.pd, e, io.pd_se, r, io.pd_sx) = (float)pd_r[r];
             if (io.snr_with) at(io.snr_with, e, io.sw_se, r, io.sw_sx) = (float)snr_rep;
@@ -778,6 +837,27 @@ __global__ void env_advance_kernel(int64_t n_envs, int32_t T, int32_t* step, con
     }
 }
 
+// One launch when a scenario is created: the derived tables of DevTables, computed with the device functions the step
+// kernels use (a host-computed reciprocal could differ from rcp_refined's in the last bit).
+__global__ void scenario_derive_kernel(DevTables* t) {
+    const int J = t->J, R = t->R;
+    for (int i = threadIdx.x; i < J * R; i += blockDim.x) {
+        const double denom = t->denom[i];
+        const uint8_t fl = t->flags[i];
+        const bool live = denom > 1e-18;
+        const double d = live ? ((fl & MACJD_JR_WEAK_DENOM) ? (double)(float)denom : denom) : 1.0;
+        t->dsel[i] = d;
+        t->rsel[i] = rcp_refined(d);
+        t->rflags[i] = (uint8_t)(fl | (denom >= 0.0 ? JR_RECORDABLE : 0) | (live ? JR_LIVE : 0));
+    }
+    for (int r = threadIdx.x; r < R; r += blockDim.x) t->rPn[r] = rcp_refined(t->Pn[r] > 1e-18 ? t->Pn[r] : 1.0);
+    for (int j = threadIdx.x; j < J; j += blockDim.x) {
+        const double rf = (double)(float)(t->pmax[j] - t->pmin[j]);
+        t->range_fd[j] = rf;
+        t->r_range[j] = rcp_refined(rf > 0.0 ? rf : 1.0);
+    }
+}
+
 }  // namespace macjd
 
 using macjd::DevTables;
@@ -824,9 +904,36 @@ int macjd_scenario_create(const macjd_scenario_desc* d, macjd_scenario** out) {
         t.pmin[j] = d->jam_pmin[j]; t.pmax[j] = d->jam_pmax[j]; t.gj[j] = d->jam_gj[j];
     }
     for (int i = 0; i < J * R; ++i) { t.denom[i] = d->jr_denom[i]; t.flags[i] = d->jr_flags[i]; }
+    // REGULAR scenario (env_step_kernel, REG): every quantity a division of the step can meet lies far inside the range
+    // where the hardware's IEEE division needs neither operand scaling nor special cases (magnitudes in [1e-30, 1e30]
+    // give quotients and residuals within 1e-220 .. 1e100), the float32 numerator cannot overflow, the noise power is
+    // positive (SNR denominators >= Pn > 1e-18, SNRs >= +0), and the probability formula's argument stays above -700.
+    {
+        auto mag = [](double v) { return v >= 1e-30 && v <= 1e30; };
+        bool ok = t.pd_denB >= 1e-9 && t.pd_denB <= 1e30 && fabs(t.pd_A) <= 1e30 && fabs(t.pd_c1) <= 1e30 &&
+                  (10.0 * t.pd_c1 - t.pd_A) / t.pd_denB >= -700.0;
+        double gr_max = 0.0, pg_max = 0.0;
+        for (int r = 0; r < R && ok; ++r) {
+            ok = mag(t.GaPs[r]) && t.Pn[r] > 1e-18 && t.Pn[r] <= 1e30 && (t.D[r] == 0.0 || mag(t.D[r])) &&
+                 (t.gr[r] == 0.0 || mag(t.gr[r]));
+            gr_max = t.gr[r] > gr_max ? t.gr[r] : gr_max;
+        }
+        for (int j = 0; j < J && ok; ++j) {
+            const double range = t.pmax[j] - t.pmin[j], pm = fabs(t.pmin[j]) > fabs(t.pmax[j]) ? fabs(t.pmin[j]) : fabs(t.pmax[j]);
+            ok = pm <= 1e30 && (t.gj[j] == 0.0 || mag(t.gj[j])) && (range <= 1e-6 || mag(range));
+            pg_max = pm * t.gj[j] > pg_max ? pm * t.gj[j] : pg_max;
+        }
+        for (int i = 0; i < J * R && ok; ++i) ok = !(t.denom[i] > 1e-18) || t.denom[i] <= 1e30;
+        t.regular = (ok && pg_max * gr_max < 1e30) ? 1 : 0;
+    }
     hipError_t err = hipGetDevice(&s->device);
     if (err == hipSuccess) err = hipMalloc((void**)&s->dev, sizeof(DevTables));
     if (err == hipSuccess) err = hipMemcpy(s->dev, &t, sizeof(DevTables), hipMemcpyHostToDevice);
+    if (err == hipSuccess) {
+        hipLaunchKernelGGL(macjd::scenario_derive_kernel, dim3(1), dim3(256), 0, (hipStream_t)0, s->dev);
+        err = hipGetLastError();
+        if (err == hipSuccess) err = hipDeviceSynchronize();
+    }
     if (err != hipSuccess) {
         if (s->dev) (void)hipFree(s->dev);
         delete s;
@@ -848,6 +955,11 @@ int macjd_scenario_dims(const macjd_scenario* s, int32_t* n_radars, int32_t* n_j
     if (n_jammers) *n_jammers = s->host.J;
     if (episode_limit) *episode_limit = s->host.episode_limit;
     return MACJD_OK;
+}
+
+int macjd_scenario_is_regular(const macjd_scenario* s) {
+    if (!s) return set_err(MACJD_EINVAL, "macjd_scenario_is_regular: NULL scenario");
+    return s->host.regular;
 }
 
 int macjd_env_reset(const macjd_scenario* s, int64_t n_envs, uint8_t* track, int64_t k_se, int64_t k_sx,
@@ -940,12 +1052,16 @@ static int launch_step(const macjd_scenario* s, const macjd_step_io* io, hipStre
             return set_err(MACJD_EUNSUPPORTED, "%s", "macjd_env_step_many: production configuration only (Philox uniforms, "
                            "float32 actions, no float64 diagnostics, offsets below 2^32 bytes)");
         }
+        const char* reg_env = getenv("MACJD_ENV_REGULAR");   // "0": keep IEEE divisions + all guards (A/B runs, tests)
+        const bool no_reg = reg_env && reg_env[0] == '0';
 #define MACJD_LAUNCH(JT, RT)                                                                                          \
     do {                                                                                                              \
         if (per_env && fast)                                                                                          \
             hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT, true, true, macjd::FastStepIO>), gf, b, 0, stream, s->dev, f);      \
         else if (per_env)                                                                                             \
             hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT, true, false, macjd_step_io>), g, b, 0, stream, s->dev, *io);        \
+        else if (fast && s->host.regular && !no_reg)                                                                  \
+            hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT, false, true, macjd::FastStepIO, true>), gf, b, 0, stream, s->dev, f); \
         else if (fast)                                                                                                \
             hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT, false, true, macjd::FastStepIO>), gf, b, 0, stream, s->dev, f);     \
         else                                                                                                          \

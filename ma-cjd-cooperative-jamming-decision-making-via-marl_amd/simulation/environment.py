@@ -334,6 +334,13 @@ class BatchedElectromagneticEnvironment:
                                                          ctypes.byref(ms)), "macjd_env_step_timed")
         return float(ms.value)
 
+    @property
+    def scenario_regular(self) -> bool:
+        """The shared scenario's tables are regular (include/macjd.h, macjd_scenario_is_regular): the production lane
+        kernel runs its short-division form.  Per-env scenario batches have no shared handle: False."""
+        h = getattr(self, "_handle", None)
+        return bool(h is not None and self._lib.macjd_scenario_is_regular(h.ptr) == 1)
+
     def close(self) -> None:
         self._handle.close()
 

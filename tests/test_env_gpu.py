@@ -506,3 +506,42 @@ def test_slot_kernel_equals_lane_kernel_bitwise(name, E):
         assert torch.equal(ra, rb) and torch.equal(ta, tb_)
         for k in ("r_d", "r_p", "r_j", "radar_tracking", "radar_pds", "snr_with_jamming", "step_count"):
             assert torch.equal(ia[k], ib[k]), (t, k)
+
+
+@pytest.mark.parametrize("name", ["2j2r_shipped", "3j4r", "6j8r", "12j16r", "3j3r_edge"])
+def test_regular_scenario_variant_equals_ieee_division_variant(name, monkeypatch):
+    """Production lane kernel of a REGULAR scenario (divisions by table values through refined reciprocals from the
+    tables, float32 quotients as twice-rounded float64 ones, guards a regular scenario cannot trigger dropped) ==
+    the same kernel with IEEE divisions and every guard (MACJD_ENV_REGULAR=0) == the general variant, on every output
+    the production configuration has, over 70 000 envs x 6 steps of random actions incl. invalid action types,
+    out-of-range / NaN powers and, in the edge scenario, a jammer sitting on a radar; and vs the oracle."""
+    from macjd_amd import _native
+    from _harness import OracleEnv
+    sc, _ = load_scenario(name)
+    R, J = sc.num_radars, sc.num_jammers
+    E = 70000 if name in ("3j4r", "3j3r_edge") else 20000
+    reg, ieee = _env(sc, E, seed=21, env_offset=5), _env(sc, E, seed=21, env_offset=5)
+    assert reg.scenario_regular, "the shipped / benchmark / edge scenarios are regular"
+    reg.kernel_flags = ieee.kernel_flags = _native.STEP_LANE_KERNEL
+    reg.reset(); ieee.reset()
+    ora = OracleEnv(sc, 4096, n_threads=8)
+    ora.reset()
+    rng = np.random.default_rng(J * 100 + R)
+    for t in range(6):
+        T, P = random_actions(rng, E, J, R)
+        P = (P * 1.6 - 0.3).astype(np.float32)          # some below 0 and above 1 (np.clip)
+        P[rng.random((E, J)) < 0.01] = np.nan           # NaN propagates through np.clip: the jammer is not recorded
+        Td, Pd = torch.from_numpy(T).cuda(), torch.from_numpy(P).cuda()
+        monkeypatch.delenv("MACJD_ENV_REGULAR", raising=False)
+        r1, t1, i1 = reg.step(Td, Pd)
+        monkeypatch.setenv("MACJD_ENV_REGULAR", "0")
+        r2, t2, i2 = ieee.step(Td, Pd)
+        same = lambda a, b: torch.equal(torch.nan_to_num(a.float(), nan=-777.0), torch.nan_to_num(b.float(), nan=-777.0))
+        assert torch.isnan(r1).any()                     # a NaN power makes r_p (and the reward) NaN, like the reference
+        assert same(r1, r2) and torch.equal(t1, t2)
+        for k in ("r_d", "r_p", "r_j", "radar_tracking", "radar_pds", "snr_with_jamming"):
+            assert same(i1[k], i2[k]), (t, k)
+        ora.step_count[:] = t
+        o = ora.step(T[:4096], P[:4096], seed=21, env_offset=5)
+        np.testing.assert_allclose(r1[:4096].cpu().numpy(), o["reward"], rtol=0, atol=1e-5)
+        np.testing.assert_array_equal(i1["radar_tracking"][:4096].cpu().numpy(), o["track"])
