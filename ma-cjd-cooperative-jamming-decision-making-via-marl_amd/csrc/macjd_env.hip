@@ -226,8 +226,10 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
     // adds into the row of the radar it chose (one ds_read / ds_write pair on the LDS port) instead of J x R
     // compare / select / fma chains on the VALU, which is the unit this kernel is bound by; row NR takes the
     // contributions of jammers that have none.  Same operations in the same (jammer) order on the same values.
-    constexpr int ACC_W = REG ? 256 : 1;
-    __shared__ double s_supp[REG ? NR + 1 : 1][ACC_W], s_prod[REG ? NR + 1 : 1][ACC_W];
+    // (also the per-env-table production variant: its lanes hold ~45 table values each, every register counts)
+    constexpr bool SCAT = REG || (PE && FAST && JT && RT);
+    constexpr int ACC_W = SCAT ? 256 : 1;
+    __shared__ double s_supp[SCAT ? NR + 1 : 1][ACC_W], s_prod[SCAT ? NR + 1 : 1][ACC_W];
     __shared__ double s_D[PE ? 1 : NR], s_Pn[PE ? 1 : NR], s_gr[PE ? 1 : NR];
     __shared__ uint8_t s_flags[PE ? 1 : NJ * NR];
     if (!PE) {
@@ -365,8 +367,8 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
         double prod[NR];   // environment.py:443-447
 #pragma unroll
         for (int r = 0; r < NR; ++r) { supp[r] = 0.0; prod[r] = 1.0; }
-        const int col = REG ? (int)threadIdx.x : 0;
-        if (REG) {
+        const int col = SCAT ? (int)threadIdx.x : 0;
+        if (SCAT) {
 #pragma unroll
             for (int r = 0; r < NR; ++r) { s_supp[r][col] = 0.0; s_prod[r][col] = 1.0; }
         }
@@ -452,7 +454,7 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
             const bool is_sup = recorded && (jtype == 1);
             const bool is_dec = recorded && (jtype == 0);
             supp_mask |= is_sup ? (1u << target) : 0u;
-            if (REG) {                     // environment.py:299
+            if (SCAT) {                    // environment.py:299
                 const int row = is_sup ? target : NR;
                 s_supp[row][col] = s_supp[row][col] + prj;
             } else {
@@ -494,7 +496,7 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
         for (int r = 0; r < NR; ++r) {
             if (!RT && r >= R) break;
             const double Pn = t_Pn(r);
-            const double den = t_D(r) * (REG ? s_supp[r][col] : supp[r]) + Pn;   // :331
+            const double den = t_D(r) * (SCAT ? s_supp[r][col] : supp[r]) + Pn;   // :331
             if (REG) {                                                       // den >= Pn > 1e-18
                 snr_w[r] = div_by_refined(t_GaPs(r), den, rcp_refined(den));
                 snr_all[r] = snr_w[r];
@@ -529,7 +531,7 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
                 const bool hit = is_dec && (u <= pd_f);                      // :430-434
                 const double safe = pd_f < 0.999999 ? pd_f : 0.999999;      // :446
                 hit_mask |= hit ? (1u << dec_tgt[j]) : 0u;
-                if (REG) {
+                if (SCAT) {
                     const int row = hit ? dec_tgt[j] : NR;
                     s_prod[row][col] = s_prod[row][col] * (1.0 - safe);
                 } else {
@@ -558,7 +560,7 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
             r_d += tracking ? t_rdpen(r) : 0.0;                             // :359-366 (post-update state)
             const double red = t_pdno(r) - pd;                               // :396-398
             r_j += ((supp_mask & (1u << r)) && red > 0.0) ? red : 0.0;
-            r_j_dec += (hit_mask & (1u << r)) ? 1.0 - (REG ? s_prod[r][col] : prod[r]) : 0.0;   // :438-451
+            r_j_dec += (hit_mask & (1u << r)) ? 1.0 - (SCAT ? s_prod[r][col] : prod[r]) : 0.0;   // :438-451
             pd_r[r] = pd;
         }
         // per-radar outputs (the only conditional code of the pass: kept behind the arithmetic)
