@@ -26,7 +26,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef MACJD_WG_KC
 #define MACJD_WG_KC 128   // rows of the reduction per workgroup (tuning knob: -DMACJD_WG_KC=64 halves LDS per workgroup)
 #endif
-constexpr int WG_BM = 64, WG_BN = 64, WG_KC = MACJD_WG_KC, WG_PITCH = 80;
+#ifndef MACJD_WG_ABLATE
+#define MACJD_WG_ABLATE 0   // timing-only builds (scripts/probe_wgrad.py): 1 no MFMA loop, 2 no global loads, 4 no partial store
+#endif
+#ifndef MACJD_WG_SUB
+#define MACJD_WG_SUB 1      // 128-row pieces per work item (2: piece s + 1 is loaded into registers while piece s is multiplied —
+                            // measured slower on the update's problems: 18.3 vs 11.7 us, half the workgroups with twice the latency each)
+#endif
+constexpr int WG_BM = 64, WG_BN = 64, WG_KC = MACJD_WG_KC, WG_PITCH = 80, WG_SUB = MACJD_WG_SUB;
+constexpr int WG_ROWS = WG_KC * WG_SUB;   // rows of the reduction per work item (= per partial tile in the workspace)
 
 __host__ __device__ inline int64_t wg_pad(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
@@ -44,40 +52,73 @@ __device__ __forceinline__ void wgrad_partial_body(const WgradProb& io, const in
                                                    float* __restrict__ sA, float* __restrict__ sB) {
     const int Mp = io.Mp, Np = io.Np;
     const int m0 = tm * WG_BM, n0 = tn * WG_BN;
-    const int64_t k0 = (int64_t)chunk * WG_KC;
+    const int64_t k0 = (int64_t)chunk * WG_ROWS;
     const int tid = threadIdx.x;
-    // ---- stage both chunks: 128 rows x 64 columns, 16 threads per row, 16-byte loads where aligned ----
-    const bool a_vec = ((io.gout_ld & 3) == 0) && ((((uintptr_t)io.gout) & 15) == 0);
-    const bool b_vec = ((io.inp_ld & 3) == 0) && ((((uintptr_t)io.inp) & 15) == 0);
+    // ---- a 128-row piece of both operands: 64 columns, 16 threads per row, 16-byte loads where aligned.  The piece is
+    // loaded into registers (8 x 2 float4 per thread) and written to LDS in a second step, so that the loads of piece
+    // s + 1 are in flight while piece s is multiplied (measured on the update's seven problems: loads ~10 us and MFMA
+    // ~8 us of the launch were additive when each work item was load -> barrier -> multiply) ----
+    // All loads are branch-free: rows past K and columns past M / N are read from CLAMPED (valid) addresses and zeroed by
+    // selects afterwards.  A load under a divergent `if` makes hipcc wait for ALL outstanding loads at the join — the
+    // first version guarded every element and so serialised its 8 x 2 row pieces, one memory latency after the other.
+    // Width of a load is uniform per operand: 16 bytes (rows 16-byte aligned, tile inside the matrix), 8 bytes (even row
+    // length: a column pair is inside or outside as a whole) or 4.
+    constexpr int NIT = (WG_KC * 16) / 256;
+    float4 va[NIT], vb[NIT];
+    auto load_operand = [&](const float* __restrict__ base, const int64_t ld, const int cols, const int c0, const int piece,
+                            float4* __restrict__ out) {
+        const bool al16 = ((ld & 3) == 0) && ((((uintptr_t)base) & 15) == 0) && (c0 + 64 <= cols);
+        const bool al8 = ((ld & 1) == 0) && ((cols & 1) == 0) && ((((uintptr_t)base) & 7) == 0) && cols >= 2;
+        const int c4 = (tid & 15) * 4;
+        int64_t roff[NIT];
+        bool rok[NIT];
 #pragma unroll
-    for (int it = 0; it < (WG_KC * 16) / 256; ++it) {
-        const int idx = it * 256 + tid;
-        const int r = idx >> 4, c4 = (idx & 15) * 4;
-        const int64_t k = k0 + r;
-        float4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
-        if (k < io.K) {
-            const float* ga = io.gout + k * io.gout_ld + m0 + c4;
-            if (a_vec && m0 + c4 + 3 < io.M) va = *reinterpret_cast<const float4*>(ga);
-            else {
-                if (m0 + c4 + 0 < io.M) va.x = ga[0];
-                if (m0 + c4 + 1 < io.M) va.y = ga[1];
-                if (m0 + c4 + 2 < io.M) va.z = ga[2];
-                if (m0 + c4 + 3 < io.M) va.w = ga[3];
-            }
-            const float* gb = io.inp + k * io.inp_ld + n0 + c4;
-            if (b_vec && n0 + c4 + 3 < io.N) vb = *reinterpret_cast<const float4*>(gb);
-            else {
-                if (n0 + c4 + 0 < io.N) vb.x = gb[0];
-                if (n0 + c4 + 1 < io.N) vb.y = gb[1];
-                if (n0 + c4 + 2 < io.N) vb.z = gb[2];
-                if (n0 + c4 + 3 < io.N) vb.w = gb[3];
-            }
+        for (int it = 0; it < NIT; ++it) {
+            const int64_t k = k0 + (int64_t)piece * WG_KC + ((it * 256 + tid) >> 4);
+            rok[it] = k < io.K && !(MACJD_WG_ABLATE & 2);
+            roff[it] = (k < io.K ? k : io.K - 1) * ld;
         }
-        *reinterpret_cast<float4*>(&sA[r * WG_PITCH + c4]) = va;
-        *reinterpret_cast<float4*>(&sB[r * WG_PITCH + c4]) = vb;
-    }
-    __syncthreads();
-    // ---- 32 x 32 per wave: acc[sm][sn] += A^T fragment x B fragment over the chunk ----
+        if (al16) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) out[it] = *reinterpret_cast<const float4*>(base + roff[it] + c0 + c4);
+        } else if (al8) {
+            const int ca = c0 + c4 < cols ? c0 + c4 : cols - 2, cb = c0 + c4 + 2 < cols ? c0 + c4 + 2 : cols - 2;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const float2 lo = *reinterpret_cast<const float2*>(base + roff[it] + ca);
+                const float2 hi = *reinterpret_cast<const float2*>(base + roff[it] + cb);
+                out[it] = float4{lo.x, lo.y, hi.x, hi.y};
+            }
+        } else {
+            int cc[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cc[e] = c0 + c4 + e < cols ? c0 + c4 + e : cols - 1;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                out[it] = float4{base[roff[it] + cc[0]], base[roff[it] + cc[1]], base[roff[it] + cc[2]], base[roff[it] + cc[3]]};
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            out[it].x = (rok[it] && c0 + c4 + 0 < cols) ? out[it].x : 0.0f;
+            out[it].y = (rok[it] && c0 + c4 + 1 < cols) ? out[it].y : 0.0f;
+            out[it].z = (rok[it] && c0 + c4 + 2 < cols) ? out[it].z : 0.0f;
+            out[it].w = (rok[it] && c0 + c4 + 3 < cols) ? out[it].w : 0.0f;
+        }
+    };
+    auto load_piece = [&](const int piece) {
+        load_operand(io.gout, io.gout_ld, io.M, m0, piece, va);
+        load_operand(io.inp, io.inp_ld, io.N, n0, piece, vb);
+    };
+    auto store_piece = [&]() {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * 256 + tid;
+            const int r = idx >> 4, c4 = (idx & 15) * 4;
+            *reinterpret_cast<float4*>(&sA[r * WG_PITCH + c4]) = va[it];
+            *reinterpret_cast<float4*>(&sB[r * WG_PITCH + c4]) = vb[it];
+        }
+    };
+    // ---- 32 x 32 per wave: acc[sm][sn] += A^T fragment x B fragment over the work item's rows ----
     const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     f32x4 acc[2][2];
@@ -87,14 +128,36 @@ __device__ __forceinline__ void wgrad_partial_body(const WgradProb& io, const in
         for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* pa = sA + lk * WG_PITCH + wm + li;
     const float* pb = sB + lk * WG_PITCH + wn + li;
+    const bool bias_lane = io.want_db && tn == 0 && tid < WG_BM;
+    float bias_sum = 0.0f;
+    const int n_pieces = (int)((((io.K - k0) < (int64_t)WG_ROWS ? (io.K - k0) : (int64_t)WG_ROWS) + WG_KC - 1) / WG_KC);
+    load_piece(0);
+    store_piece();
+    __syncthreads();
+    for (int piece = 0; piece < n_pieces; ++piece) {
+        const bool more = piece + 1 < n_pieces;
+        if (more) load_piece(piece + 1);       // in flight during the products below
 #pragma unroll 8
-    for (int kk = 0; kk < WG_KC / 4; ++kk) {
-        const float a0 = pa[kk * 4 * WG_PITCH], a1 = pa[kk * 4 * WG_PITCH + 16];
-        const float b0 = pb[kk * 4 * WG_PITCH], b1 = pb[kk * 4 * WG_PITCH + 16];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int kk = 0; kk < ((MACJD_WG_ABLATE & 1) ? 1 : WG_KC / 4); ++kk) {
+            const float a0 = pa[kk * 4 * WG_PITCH], a1 = pa[kk * 4 * WG_PITCH + 16];
+            const float b0 = pb[kk * 4 * WG_PITCH], b1 = pb[kk * 4 * WG_PITCH + 16];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        // bias partial: column sums of the staged gout piece (N-tile 0 only), pieces added in order
+        if (bias_lane) {
+            float sp = 0.0f;
+#pragma unroll 8
+            for (int r = 0; r < WG_KC; ++r) sp += sA[r * WG_PITCH + tid];
+            bias_sum += sp;
+        }
+        if (more) {
+            __syncthreads();                   // every wave is done reading this piece
+            store_piece();
+            __syncthreads();
+        }
     }
     float* ws = io.workspace + (int64_t)chunk * Mp * Np;
 #pragma unroll
@@ -105,15 +168,9 @@ __device__ __forceinline__ void wgrad_partial_body(const WgradProb& io, const in
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm + a * 16 + lk * 4 + r;   // C layout: row = (lane >> 4) * 4 + reg
                 const int n = n0 + wn + b * 16 + li;           //           col = lane & 15
-                ws[(int64_t)m * Np + n] = acc[a][b][r];
+                if (!(MACJD_WG_ABLATE & 4) || acc[a][b][r] == 12345.678f) ws[(int64_t)m * Np + n] = acc[a][b][r];
             }
-    // ---- bias partial: column sums of the staged gout chunk (N-tile 0 only) ----
-    if (io.want_db && tn == 0 && tid < WG_BM) {
-        float s = 0.0f;
-#pragma unroll 8
-        for (int r = 0; r < WG_KC; ++r) s += sA[r * WG_PITCH + tid];
-        io.workspace[(int64_t)io.n_chunks * Mp * Np + (int64_t)chunk * Mp + m0 + tid] = s;
-    }
+    if (bias_lane) io.workspace[(int64_t)io.n_chunks * Mp * Np + (int64_t)chunk * Mp + m0 + tid] = bias_sum;
 }
 
 __global__ void __launch_bounds__(256) wgrad_partial_kernel(const macjd_wgrad_io io, const int Mp, const int Np) {
@@ -125,37 +182,39 @@ __global__ void __launch_bounds__(256) wgrad_partial_kernel(const macjd_wgrad_io
     wgrad_partial_body(p, blockIdx.x, blockIdx.y, blockIdx.z, sA, sB);
 }
 
-// Sum of the K-chunk partials, fixed order (deterministic).  8 lanes share one output element: lane s of the group adds
-// chunks s, s+8, s+16, ... (independent loads in flight), then a 3-step xor-shuffle tree combines the 8 partial sums.
+// Sum of the K-chunk partials, fixed order (deterministic): one lane per output element, consecutive lanes = consecutive
+// n (every load instruction of a wave reads one contiguous row piece of a partial tile), eight accumulators per lane —
+// accumulator s takes chunks s, s + 8, s + 16, ... — combined as ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)).
+// (The first version spread an output's chunks over 8 LANES: 32-byte pieces of eight different tiles per load, 11 us for
+// the update's problems; same summation order.)
+__device__ __forceinline__ float wgrad_sum_chunks(const float* __restrict__ p, const int64_t stride, const int n_chunks) {
+    float a[8];
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) a[s8] = 0.0f;
+    int c = 0;
+    for (; c + 8 <= n_chunks; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) v[s8] = p[(int64_t)(c + s8) * stride];
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) a[s8] += v[s8];
+    }
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8)
+        if (c + s8 < n_chunks) a[s8] += p[(int64_t)(c + s8) * stride];
+    return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const macjd_wgrad_io io, const int Mp, const int Np,
                                                            const int n_chunks) {
     const int64_t total = (int64_t)io.M * io.N;
-    const int sub = threadIdx.x & 7;
-    const int64_t groups_per_block = blockDim.x >> 3;
-    for (int64_t i = (int64_t)blockIdx.x * groups_per_block + (threadIdx.x >> 3); i < total + io.M;
-         i += (int64_t)gridDim.x * groups_per_block) {
-        float s = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total + io.M; i += (int64_t)gridDim.x * blockDim.x) {
         if (i < total) {
             const int m = (int)(i / io.N), n = (int)(i - (int64_t)m * io.N);
-            const float* p = io.workspace + (int64_t)m * Np + n;
-#pragma unroll 4
-            for (int c = sub; c < n_chunks; c += 8) s += p[(int64_t)c * Mp * Np];
+            io.dW[(int64_t)m * io.dw_ld + n] = wgrad_sum_chunks(io.workspace + (int64_t)m * Np + n, (int64_t)Mp * Np, n_chunks);
         } else if (io.db) {
             const int m = (int)(i - total);
-            const float* p = io.workspace + (int64_t)n_chunks * Mp * Np + m;
-#pragma unroll 4
-            for (int c = sub; c < n_chunks; c += 8) s += p[(int64_t)c * Mp];
-        }
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 4, 64);
-        if (sub == 0) {
-            if (i < total) {
-                const int m = (int)(i / io.N), n = (int)(i - (int64_t)m * io.N);
-                io.dW[(int64_t)m * io.dw_ld + n] = s;
-            } else if (io.db) {
-                io.db[i - total] = s;
-            }
+            io.db[m] = wgrad_sum_chunks(io.workspace + (int64_t)n_chunks * Mp * Np + m, Mp, n_chunks);
         }
     }
 }
@@ -197,11 +256,8 @@ __global__ void __launch_bounds__(256) wgrad_partial_many_kernel(const WgradBatc
 }
 
 __global__ void __launch_bounds__(256) wgrad_reduce_many_kernel(const WgradBatch b) {
-    const int sub = threadIdx.x & 7;
-    const int64_t groups_per_block = blockDim.x >> 3;
     const int64_t total_all = b.out_start[b.n];
-    for (int64_t g = (int64_t)blockIdx.x * groups_per_block + (threadIdx.x >> 3); g < total_all;
-         g += (int64_t)gridDim.x * groups_per_block) {
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total_all; g += (int64_t)gridDim.x * blockDim.x) {
         int M = b.io[0].M, N = b.io[0].N, Mp = b.Mp[0], Np = b.Np[0], n_chunks = b.chunks[0];
         int64_t start = 0, dw_ld = b.io[0].dw_ld;
         const float* workspace = b.io[0].workspace;
@@ -216,28 +272,12 @@ __global__ void __launch_bounds__(256) wgrad_reduce_many_kernel(const WgradBatch
         }
         const int64_t i = g - start;
         const int64_t total = (int64_t)M * N;
-        float s = 0.0f;
         if (i < total) {
             const int m = (int)(i / N), n = (int)(i - (int64_t)m * N);
-            const float* ptr = workspace + (int64_t)m * Np + n;
-#pragma unroll 4
-            for (int c = sub; c < n_chunks; c += 8) s += ptr[(int64_t)c * Mp * Np];
+            dW[(int64_t)m * dw_ld + n] = wgrad_sum_chunks(workspace + (int64_t)m * Np + n, (int64_t)Mp * Np, n_chunks);
         } else if (db) {
             const int m = (int)(i - total);
-            const float* ptr = workspace + (int64_t)n_chunks * Mp * Np + m;
-#pragma unroll 4
-            for (int c = sub; c < n_chunks; c += 8) s += ptr[(int64_t)c * Mp];
-        }
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 4, 64);
-        if (sub == 0) {
-            if (i < total) {
-                const int m = (int)(i / N), n = (int)(i - (int64_t)m * N);
-                dW[(int64_t)m * dw_ld + n] = s;
-            } else if (db) {
-                db[i - total] = s;
-            }
+            db[m] = wgrad_sum_chunks(workspace + (int64_t)n_chunks * Mp * Np + m, Mp, n_chunks);
         }
     }
 }
@@ -247,7 +287,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_many_kernel(const WgradBatch
 extern "C" int64_t macjd_linear_wgrad_workspace_floats(int64_t K, int32_t M, int32_t N) {
     using namespace macjd;
     if (K < 1 || M < 1 || N < 1) return -1;
-    const int64_t chunks = (K + WG_KC - 1) / WG_KC, Mp = wg_pad(M, WG_BM), Np = wg_pad(N, WG_BN);
+    const int64_t chunks = (K + WG_ROWS - 1) / WG_ROWS, Mp = wg_pad(M, WG_BM), Np = wg_pad(N, WG_BN);
     return chunks * Mp * Np + chunks * Mp;
 }
 
@@ -258,12 +298,12 @@ extern "C" int macjd_linear_wgrad(const macjd_wgrad_io* io, void* hip_stream) {
     if (io->gout_ld < io->M || io->inp_ld < io->N || io->dw_ld < io->N)
         return set_err(MACJD_EINVAL, "%s", "macjd_linear_wgrad: bad leading dimension");
     const int Mp = (int)wg_pad(io->M, WG_BM), Np = (int)wg_pad(io->N, WG_BN);
-    const int64_t chunks = (io->K + WG_KC - 1) / WG_KC;
+    const int64_t chunks = (io->K + WG_ROWS - 1) / WG_ROWS;
     if (chunks > 65535) return set_err(MACJD_EUNSUPPORTED, "%s", "macjd_linear_wgrad: K too large");
     hipStream_t s = (hipStream_t)hip_stream;
     hipLaunchKernelGGL(wgrad_partial_kernel, dim3(Np / WG_BN, Mp / WG_BM, (unsigned)chunks), dim3(256), 0, s, *io, Mp, Np);
-    const int64_t total = (int64_t)io->M * io->N + io->M;   // 8 lanes per output element -> 32 outputs per block
-    const unsigned rblocks = (unsigned)((total + 31) / 32 < 2048 ? (total + 31) / 32 : 2048);
+    const int64_t total = (int64_t)io->M * io->N + io->M;   // one lane per output element
+    const unsigned rblocks = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, s, *io, Mp, Np, (int)chunks);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_linear_wgrad: %s", hipGetErrorString(err));
@@ -285,7 +325,7 @@ extern "C" int macjd_linear_wgrad_many(const macjd_wgrad_io* ios, int32_t n, voi
         b.io[p] = *io;
         b.Mp[p] = (int)wg_pad(io->M, WG_BM);
         b.Np[p] = (int)wg_pad(io->N, WG_BN);
-        b.chunks[p] = (int)((io->K + WG_KC - 1) / WG_KC);
+        b.chunks[p] = (int)((io->K + WG_ROWS - 1) / WG_ROWS);
         b.tiles_n[p] = b.Np[p] / WG_BN;
         b.tiles_m[p] = b.Mp[p] / WG_BM;
         b.wg_start[p + 1] = b.wg_start[p] + (int64_t)b.tiles_n[p] * b.tiles_m[p] * b.chunks[p];
@@ -300,7 +340,7 @@ extern "C" int macjd_linear_wgrad_many(const macjd_wgrad_io* ios, int32_t n, voi
     hipStream_t s = (hipStream_t)hip_stream;
     hipLaunchKernelGGL(wgrad_partial_many_kernel, dim3((unsigned)b.wg_start[n]), dim3(256), 0, s, b);
     const int64_t total = b.out_start[n];
-    const unsigned rblocks = (unsigned)((total + 31) / 32 < 4096 ? (total + 31) / 32 : 4096);
+    const unsigned rblocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3(rblocks), dim3(256), 0, s, b);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_linear_wgrad_many: %s", hipGetErrorString(err));

@@ -908,6 +908,10 @@ class deferred_wgrad:
         if exc[0] is None and pending:
             lib = _native.load()
             dev = pending[0][1][0].device
+            if os.environ.get("MACJD_WGRAD_DEBUG") == "1":   # the problem list of a flush (shapes, strides, alignment)
+                for io, _ in pending:
+                    print(f"[wgrad] K={io.K} M={io.M} N={io.N} gout_ld={io.gout_ld} (ptr%16={io.gout % 16}) "
+                          f"inp_ld={io.inp_ld} (ptr%16={io.inp % 16}) dw_ld={io.dw_ld} db={'y' if io.db else 'n'}", flush=True)
             for lo in range(0, len(pending), 8):
                 part = pending[lo:lo + 8]
                 arr = (_native.WgradIO * len(part))(*[io for io, _ in part])
