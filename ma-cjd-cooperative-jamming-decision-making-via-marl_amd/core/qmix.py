@@ -438,11 +438,16 @@ class QMixLearner:
             p.grad = None
         if eval_q_tot.is_cuda:
             # the loss kernel also produces dL/dQ_tot: it seeds the backward pass directly (no ones-fill / multiply)
-            loss, eval_mean, target_mean, gy, self._last_stats4 = ops.td_loss_and_grad(
+            # the TD loss (+ its gradient and the logged means) is computed inside the eval mixer's ONE backward launch
+            # when that mixer ran fused; otherwise by its own launch, which also yields the gradient that seeds the pass
+            in_mixer = os.environ.get("MACJD_TD_IN_MIXER", "1") != "0" and ops.fused_mixer_backward_will_run(eval_q_tot)
+            td = ops.td_loss_in_mixer_backward if in_mixer else ops.td_loss_and_grad
+            loss, eval_mean, target_mean, gy, self._last_stats4 = td(
                 eval_q_tot, target_q_tot, st["reward"], st["terminated"], st["filled"], self.args.gamma, T - 1, 1)
             # the weight gradients: one grouped launch pair after the chain, written into the flat gradient vector
             with ops.deferred_wgrad(grad_dst=getattr(self, "_grad_dst", None)):
                 eval_q_tot.backward(gy)
+            assert ops._PENDING_TD is None, "the fused mixer's backward did not take the TD loss"
         else:
             loss, eval_mean, target_mean = ops.td_loss_full(eval_q_tot, target_q_tot, st["reward"], st["terminated"],
                                                             st["filled"], self.args.gamma, T - 1, 1)

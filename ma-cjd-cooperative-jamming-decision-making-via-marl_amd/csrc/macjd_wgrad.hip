@@ -46,6 +46,8 @@ struct WgradProb {
     const float* inp;
     float* workspace;
     bool want_db;
+    const float* outer_vec;   // see macjd_wgrad_io
+    const float* outer_w;
 };
 
 __device__ __forceinline__ void wgrad_partial_body(const WgradProb& io, const int tn, const int tm, const int chunk,
@@ -108,6 +110,21 @@ __device__ __forceinline__ void wgrad_partial_body(const WgradProb& io, const in
     auto load_piece = [&](const int piece) {
         load_operand(io.gout, io.gout_ld, io.M, m0, piece, va);
         load_operand(io.inp, io.inp_ld, io.N, n0, piece, vb);
+        if (io.outer_vec) {   // (uniform) operand formed on the fly: (relu output > 0) ? vec[k] * w[m] : 0 — the very
+            const int c4 = (tid & 15) * 4;   // expression of splitrelu_backward_kernel, so the products are bit-identical
+            float w4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w4[e] = io.outer_w[m0 + c4 + e < io.M ? m0 + c4 + e : io.M - 1];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int64_t k = k0 + (int64_t)piece * WG_KC + ((it * 256 + tid) >> 4);
+                const float gv = io.outer_vec[k < io.K ? k : io.K - 1];
+                va[it].x = (va[it].x > 0.0f) ? gv * w4[0] : 0.0f;
+                va[it].y = (va[it].y > 0.0f) ? gv * w4[1] : 0.0f;
+                va[it].z = (va[it].z > 0.0f) ? gv * w4[2] : 0.0f;
+                va[it].w = (va[it].w > 0.0f) ? gv * w4[3] : 0.0f;
+            }
+        }
     };
     auto store_piece = [&]() {
 #pragma unroll
@@ -179,6 +196,7 @@ __global__ void __launch_bounds__(256) wgrad_partial_kernel(const macjd_wgrad_io
     WgradProb p;
     p.K = io.K; p.gout_ld = io.gout_ld; p.inp_ld = io.inp_ld; p.M = io.M; p.N = io.N; p.Mp = Mp; p.Np = Np;
     p.n_chunks = (int)gridDim.z; p.gout = io.gout; p.inp = io.inp; p.workspace = io.workspace; p.want_db = io.db != nullptr;
+    p.outer_vec = io.outer_vec; p.outer_w = io.outer_w;
     wgrad_partial_body(p, blockIdx.x, blockIdx.y, blockIdx.z, sA, sB);
 }
 
@@ -242,6 +260,7 @@ __global__ void __launch_bounds__(256) wgrad_partial_many_kernel(const WgradBatc
     p.K = b.io[q].K; p.gout_ld = b.io[q].gout_ld; p.inp_ld = b.io[q].inp_ld; p.M = b.io[q].M; p.N = b.io[q].N;       \
     p.Mp = b.Mp[q]; p.Np = b.Np[q]; p.n_chunks = b.chunks[q]; p.gout = b.io[q].gout; p.inp = b.io[q].inp;            \
     p.workspace = b.io[q].workspace; p.want_db = b.io[q].db != nullptr; tiles_n = b.tiles_n[q]; tiles_m = b.tiles_m[q]; \
+    p.outer_vec = b.io[q].outer_vec; p.outer_w = b.io[q].outer_w;                                                    \
     start = b.wg_start[q];
     MACJD_PICK(0)
 #pragma unroll
@@ -297,6 +316,8 @@ extern "C" int macjd_linear_wgrad(const macjd_wgrad_io* io, void* hip_stream) {
         return set_err(MACJD_EINVAL, "%s", "macjd_linear_wgrad: bad argument");
     if (io->gout_ld < io->M || io->inp_ld < io->N || io->dw_ld < io->N)
         return set_err(MACJD_EINVAL, "%s", "macjd_linear_wgrad: bad leading dimension");
+    if ((io->outer_vec == nullptr) != (io->outer_w == nullptr))
+        return set_err(MACJD_EINVAL, "%s", "macjd_linear_wgrad: outer_vec and outer_w go together");
     const int Mp = (int)wg_pad(io->M, WG_BM), Np = (int)wg_pad(io->N, WG_BN);
     const int64_t chunks = (io->K + WG_ROWS - 1) / WG_ROWS;
     if (chunks > 65535) return set_err(MACJD_EUNSUPPORTED, "%s", "macjd_linear_wgrad: K too large");
@@ -322,6 +343,8 @@ extern "C" int macjd_linear_wgrad_many(const macjd_wgrad_io* ios, int32_t n, voi
             return set_err(MACJD_EINVAL, "%s", "macjd_linear_wgrad_many: bad argument");
         if (io->gout_ld < io->M || io->inp_ld < io->N || io->dw_ld < io->N)
             return set_err(MACJD_EINVAL, "%s", "macjd_linear_wgrad_many: bad leading dimension");
+        if ((io->outer_vec == nullptr) != (io->outer_w == nullptr))
+            return set_err(MACJD_EINVAL, "%s", "macjd_linear_wgrad_many: outer_vec and outer_w go together");
         b.io[p] = *io;
         b.Mp[p] = (int)wg_pad(io->M, WG_BM);
         b.Np[p] = (int)wg_pad(io->N, WG_BN);

@@ -555,8 +555,15 @@ class _FusedMixer(torch.autograd.Function):
         io = _mixerf_io(q, None, params)
         io.act, io.gy, io.gq, io.gout1 = act.data_ptr(), gy.data_ptr(), gq.data_ptr(), gout1.data_ptr()
         io.g_w1raw, io.g_wfraw, io.g_v = g_w1.data_ptr(), g_wf.data_ptr(), g_v.data_ptr()
+        global _PENDING_TD
+        pend, _PENDING_TD = _PENDING_TD, None
         with torch.cuda.device(dev):
-            _native.check(lib.macjd_mixer_fused_backward(ctypes.byref(io), _stream(q)), "macjd_mixer_fused_backward")
+            if pend is not None:   # the TD loss rides in this launch: `gy` is a placeholder (td_loss_in_mixer_backward)
+                assert pend[2] == M, "td_loss_in_mixer_backward: the loss rows are not this mixer's rows"
+                _native.check(lib.macjd_mixer_fused_backward_td(ctypes.byref(io), ctypes.byref(pend[0]), _stream(q)),
+                              "macjd_mixer_fused_backward_td")
+            else:
+                _native.check(lib.macjd_mixer_fused_backward(ctypes.byref(io), _stream(q)), "macjd_mixer_fused_backward")
         nd = ctx.needs_input_grad
         # weight / bias gradients: split-K products of the matrices the kernel wrote (recorded inside deferred_wgrad)
         gW1, gb1 = linear_wgrad(gout1, sn, want_bias=True, w_key=grad_key(w_cat), b_key=ctx.keys["b_cat"])
@@ -781,6 +788,47 @@ def td_loss_and_grad(y_full, tq_full, reward, terminated, filled, gamma, Tm1, tq
     return stats[0], stats[1], stats[2], stats.saved_gy, stats
 
 
+_PENDING_TD = None   # TD-loss inputs waiting for the fused mixer's backward launch (td_loss_in_mixer_backward)
+
+
+def fused_mixer_backward_will_run(y_full) -> bool:
+    """``y_full`` is the output of the fused mixer node (possibly behind views): its backward is ONE launch that can take
+    the TD loss in (macjd_mixer_fused_backward_td)."""
+    fn = getattr(y_full, "grad_fn", None)
+    for _ in range(4):
+        if fn is None:
+            return False
+        if type(fn).__name__.startswith("_FusedMixer"):
+            return True
+        nxt = [f for f, _ in fn.next_functions if f is not None]
+        if len(nxt) != 1:
+            return False
+        fn = nxt[0]
+    return False
+
+
+def td_loss_in_mixer_backward(y_full, tq_full, reward, terminated, filled, gamma, Tm1, tq_off):
+    """Like ``td_loss_and_grad`` but nothing is launched now: the loss, its statistics and the gradient are computed
+    INSIDE the fused mixer's backward launch, which the caller starts with ``y_full.backward(placeholder)``.  Returns
+    (loss, mean y, mean target, placeholder, stats [4]) — the scalars are views of ``stats``, valid after the backward."""
+    global _PENDING_TD
+    B, Ty = y_full.shape[0], y_full.shape[1]
+    yc, tqc = y_full.detach().float().contiguous(), tq_full.detach().float().contiguous()
+    stats = torch.empty(4, dtype=torch.float32, device=yc.device)
+    io = _native.TdLossIO()
+    io.B, io.Tm1, io.gamma = B, int(Tm1), float(gamma)
+    io.y, io.y_sb = yc.data_ptr(), Ty
+    io.tq, io.tq_sb = tqc.data_ptr() + 4 * int(tq_off), tqc.shape[1]
+    io.gy, io.gy_sb, io.gy_cols = None, Ty, Ty
+    io.reward, io.r_sb, io.r_st = reward.data_ptr(), reward.stride(0), reward.stride(1)
+    io.terminated, io.t_sb, io.t_st = terminated.data_ptr(), terminated.stride(0), terminated.stride(1)
+    io.filled, io.f_sb, io.f_st = filled.data_ptr(), filled.stride(0), filled.stride(1)
+    io.stats = stats.data_ptr()
+    _PENDING_TD = (io, (yc, tqc, reward, terminated, filled, stats), B * Ty)
+    placeholder = torch.empty((B, Ty, 1), dtype=torch.float32, device=yc.device)   # never read
+    return stats[0], stats[1], stats[2], placeholder, stats
+
+
 def td_loss(y, tq, reward, terminated, filled, gamma):
     """(loss, mean(y), mean(target)) with loss differentiable in y.  One fused launch on a HIP device."""
     ok = (y.is_cuda and reward.dtype == torch.float32 and terminated.dtype == torch.bool and filled.dtype == torch.bool
@@ -920,7 +968,7 @@ class deferred_wgrad:
                                   "macjd_linear_wgrad_many")
 
 
-def linear_wgrad(gout, inp, want_bias=True, w_key=None, b_key=None, need=(True, True)):
+def linear_wgrad(gout, inp, want_bias=True, w_key=None, b_key=None, need=(True, True), outer=None):
     """dW [M,N] = gout[K,M]^T inp[K,N], db [M] = column sums of gout (HIP device, float32, row-strided inputs).
     ``w_key`` / ``b_key`` = grad_key of the parameters these are the gradients of: when the active ``deferred_wgrad``
     context maps them to destinations, the results are written there.  ``need`` = which of (dW, db) the caller hands
@@ -930,6 +978,11 @@ def linear_wgrad(gout, inp, want_bias=True, w_key=None, b_key=None, need=(True, 
     gout, inp = _f32c(gout), _f32c(inp)
     K, M = gout.shape
     N = inp.shape[1]
+    if outer is not None:
+        # ``gout`` is a ReLU's OUTPUT and the [K, M] operand is (gout > 0) ? vec[k] * w[m] : 0, formed while the kernel
+        # stages it (include/macjd_nets.h, macjd_wgrad_io.outer_vec): no launch materialises the product
+        o_vec, o_w = _f32c(outer[0]).reshape(-1).contiguous(), _f32c(outer[1]).reshape(-1).contiguous()
+        assert o_vec.numel() == K and o_w.numel() == M
     dW = _grad_dst(w_key, (M, N))
     if dW is None:
         dW = torch.empty((M, N), dtype=torch.float32, device=gout.device)
@@ -943,6 +996,8 @@ def linear_wgrad(gout, inp, want_bias=True, w_key=None, b_key=None, need=(True, 
     io.K, io.M, io.N = K, M, N
     io.gout, io.gout_ld, io.inp, io.inp_ld = gout.data_ptr(), gout.stride(0), inp.data_ptr(), inp.stride(0)
     io.dW, io.dw_ld, io.db, io.workspace = dW.data_ptr(), dW.stride(0), (db.data_ptr() if want_bias else None), ws.data_ptr()
+    if outer is not None:
+        io.outer_vec, io.outer_w = o_vec.data_ptr(), o_w.data_ptr()
     if _DEFERRED_WGRAD is not None and any(k is not None and k in _DEFERRED_SEEN for k in (w_key, b_key)):
         # a parameter used twice in the graph: autograd ADDS this gradient to the first one as soon as it gets it, so
         # the recorded ones must be in memory by then — run them now, and this one immediately
@@ -957,7 +1012,7 @@ def linear_wgrad(gout, inp, want_bias=True, w_key=None, b_key=None, need=(True, 
         # AccumulateGrad only adopts a gradient tensor it is the sole owner of — with a second reference it would
         # clone the still unfilled buffer into .grad right away (the flush would then fill a tensor nobody reads)
         unowned = tuple(t for t, n in ((dW, need[0]), (db, need[1])) if t is not None and not n)
-        _DEFERRED_WGRAD.append((io, (ws, gout, inp) + unowned))
+        _DEFERRED_WGRAD.append((io, (ws, gout, inp) + unowned + ((o_vec, o_w) if outer is not None else ())))
         return dW, db
     with torch.cuda.device(gout.device):
         _native.check(lib.macjd_linear_wgrad(ctypes.byref(io), _stream(gout)), "macjd_linear_wgrad")
@@ -1319,12 +1374,20 @@ class _LinearReluRowDot(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gq):
         x, w1, y, w2 = ctx.saved_tensors
-        g = _splitrelu_backward_launch(y, [y.shape[1]], 0, [gq], None, [w2])
-        gx = g.matmul(w1) if ctx.needs_input_grad[0] else None
         nd = ctx.needs_input_grad
         gW1 = gb1 = gW2 = gb2 = None
-        if nd[1] or nd[2]:
-            gW1, gb1 = linear_wgrad(g, x, want_bias=True, w_key=grad_key(w1), b_key=ctx.b1_key, need=(nd[1], nd[2]))
+        if nd[0] or os.environ.get("MACJD_WGRAD_OUTER", "1") == "0":
+            g = _splitrelu_backward_launch(y, [y.shape[1]], 0, [gq], None, [w2])   # gq w2 masked by the ReLU, [n, H]
+            gx = g.matmul(w1) if nd[0] else None
+            if nd[1] or nd[2]:
+                gW1, gb1 = linear_wgrad(g, x, want_bias=True, w_key=grad_key(w1), b_key=ctx.b1_key, need=(nd[1], nd[2]))
+        else:
+            # nobody wants the input gradient (the learner's case: the Q-head's input is data): that product is only
+            # the first layer's weight-gradient operand, which the weight-gradient kernel forms while staging it
+            gx = None
+            if nd[1] or nd[2]:
+                gW1, gb1 = linear_wgrad(y, x, want_bias=True, w_key=grad_key(w1), b_key=ctx.b1_key, need=(nd[1], nd[2]),
+                                        outer=(gq, w2))
         if nd[3] or (ctx.has_b2 and nd[4]):
             gW2, gb2 = linear_wgrad(gq.reshape(-1, 1), y, want_bias=ctx.has_b2, w_key=grad_key(w2), b_key=ctx.b2_key,
                                     need=(nd[3], ctx.has_b2 and nd[4]))

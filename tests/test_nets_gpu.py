@@ -1745,3 +1745,85 @@ def test_updates_grouped_into_one_graph_equal_single_updates():
     assert joint.train_step == n and joint.last_target_update_step == 5
     for (k_, a), b in zip(mac_1.agent.state_dict().items(), mac_j.agent.state_dict().values()):
         assert torch.equal(a, b), k_
+
+
+@pytest.mark.parametrize("deferred", [False, True])
+@pytest.mark.parametrize("N,K,Hd", [(9696, 74, 64), (1500, 33, 20)])
+def test_relu_backward_operand_formed_inside_the_weight_gradient_kernel(N, K, Hd, deferred, monkeypatch):
+    """The Q-head node's backward when nobody wants the input gradient (the learner's case): the product
+    gq w2 masked by the ReLU is formed by the weight-gradient kernel while it stages its operand
+    (macjd_wgrad_io.outer_vec) == materialising it with the ReLU-backward launch first (MACJD_WGRAD_OUTER=0): all four
+    parameter gradients bitwise, alone and inside a deferred group; ragged sizes too."""
+    from macjd_amd import ops
+    g = torch.Generator().manual_seed(N + K)
+    x = torch.randn(N, K, generator=g).to(DEV)
+    w1 = (torch.randn(Hd, K, generator=g) * 0.2).to(DEV).requires_grad_(True)
+    b1 = torch.randn(Hd, generator=g).to(DEV).requires_grad_(True)
+    w2 = torch.randn(1, Hd, generator=g).to(DEV).requires_grad_(True)
+    b2 = torch.randn(1, generator=g).to(DEV).requires_grad_(True)
+    up = torch.randn(N, 1, generator=g).to(DEV)
+    ps = (w1, b1, w2, b2)
+
+    def run(outer):
+        monkeypatch.setenv("MACJD_WGRAD_OUTER", "1" if outer else "0")
+        for t in ps:
+            t.grad = None
+        q = ops.linear_relu_dot(x, w1, b1, w2, b2)
+        assert type(q.grad_fn).__name__.startswith("_LinearReluRowDot")
+        if deferred:
+            with ops.deferred_wgrad():
+                (q * up).sum().backward()
+        else:
+            (q * up).sum().backward()
+        return [t.grad.clone() for t in ps]
+
+    ref, got = run(False), run(True)
+    for a, c in zip(ref, got):
+        assert torch.equal(a, c)
+    # and against stock autograd
+    for t in ps:
+        t.grad = None
+    (torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(x, w1, b1)), w2, b2) * up).sum().backward()
+    for t, c in zip(ps, got):
+        np.testing.assert_allclose(c.cpu().numpy(), t.grad.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(t.grad.abs().max()))
+
+
+@pytest.mark.parametrize("B,T1", [(32, 101), (3, 7)])
+def test_td_loss_inside_the_fused_mixer_backward(B, T1):
+    """macjd_mixer_fused_backward_td: the TD loss, its four logged scalars and dL/dQ_tot computed inside the eval mixer's
+    backward launch == the separate TD-loss launch followed by the plain backward launch — statistics and every gradient
+    bitwise (the in-kernel sums follow td_loss_kernel's order)."""
+    from macjd_amd import ops
+    from macjd_amd.core.networks import QMixer
+    g, d = load("3j4r_h64")
+    args = _gpu_args(d)
+    torch.manual_seed(4)
+    with quiet():
+        mixer = QMixer(args).to(DEV)
+    mixer.load_state_dict(sd_from(g, "g5_mixer0."))
+    J, S = d["J"], d["S"]
+    gen = torch.Generator().manual_seed(B)
+    state = torch.randn(B, T1, S, generator=gen).to(DEV)
+    q0 = torch.randn(B, T1, J, generator=gen).to(DEV)
+    tq = torch.randn(B, T1, 1, generator=gen).to(DEV)
+    reward = torch.randn(B, T1 - 1, 1, generator=gen).to(DEV)
+    term = (torch.rand(B, T1 - 1, 1, generator=gen) < 0.1).to(DEV)
+    filled = (torch.rand(B, T1 - 1, 1, generator=gen) < 0.9).to(DEV)
+    assert mixer.fused_available(state)
+
+    def run(in_mixer):
+        q = q0.clone().requires_grad_(True)
+        for p_ in mixer.parameters():
+            p_.grad = None
+        y = mixer(q, state)
+        assert ops.fused_mixer_backward_will_run(y)
+        f = ops.td_loss_in_mixer_backward if in_mixer else ops.td_loss_and_grad
+        loss, my, mt, gy, stats = f(y, tq, reward, term, filled, 0.99, T1 - 2, 1)
+        y.backward(gy)
+        assert ops._PENDING_TD is None
+        return [stats.clone(), q.grad.clone()] + [p_.grad.clone() for p_ in mixer.parameters()]
+
+    ref, got = run(False), run(True)
+    assert float(ref[0][3]) > 0 and torch.isfinite(ref[0]).all()
+    for a, c in zip(ref, got):
+        assert torch.equal(a, c)
