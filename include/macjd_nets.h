@@ -442,12 +442,6 @@ typedef struct macjd_mixerf_io {
 int macjd_mixer_fused_supported(int32_t J, int32_t S, int32_t Hh, int32_t Em);   /* 1 / 0 */
 int macjd_mixer_fused_forward(const macjd_mixerf_io* io, void* hip_stream);
 int macjd_mixer_fused_backward(const macjd_mixerf_io* io, void* hip_stream);
-/* macjd_mixer_fused_backward with the learner's TD loss (macjd_td_loss: core/qmix.py:155,190-194) inside the launch:
-   io->gy is not read — the gradient of the loss w.r.t. this mixer's output is formed from the loss's inputs (td->y = the
-   forward's output, rows = td->B x td->gy_cols, loss over the first td->Tm1 steps of every row block), td->stats receives
-   (loss, mean y, mean target, mask sum) bit-identical to macjd_td_loss, td->gy is not written.  One launch less on the
-   update's serial chain. */
-int macjd_mixer_fused_backward_td(const macjd_mixerf_io* io, const macjd_tdloss_io* td, void* hip_stream);
 
 /*
  * The agent side of a WHOLE episode batch in one launch: for t = 0 .. T-1 and every (env, agent) row

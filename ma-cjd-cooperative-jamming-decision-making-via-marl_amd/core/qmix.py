@@ -437,17 +437,14 @@ class QMixLearner:
         for p in self.params:
             p.grad = None
         if eval_q_tot.is_cuda:
-            # the loss kernel also produces dL/dQ_tot: it seeds the backward pass directly (no ones-fill / multiply)
-            # the TD loss (+ its gradient and the logged means) is computed inside the eval mixer's ONE backward launch
-            # when that mixer ran fused; otherwise by its own launch, which also yields the gradient that seeds the pass
-            in_mixer = os.environ.get("MACJD_TD_IN_MIXER", "1") != "0" and ops.fused_mixer_backward_will_run(eval_q_tot)
-            td = ops.td_loss_in_mixer_backward if in_mixer else ops.td_loss_and_grad
-            loss, eval_mean, target_mean, gy, self._last_stats4 = td(
+            # the loss kernel also produces dL/dQ_tot: it seeds the backward pass directly (no ones-fill / multiply).
+            # (Measured and dropped: the loss inside the eval mixer's backward launch — its loads and reductions in front of
+            # the kernel's chain cost the 7 us the separate launch does: 26.2 vs 7.5 + 17.8 us.)
+            loss, eval_mean, target_mean, gy, self._last_stats4 = ops.td_loss_and_grad(
                 eval_q_tot, target_q_tot, st["reward"], st["terminated"], st["filled"], self.args.gamma, T - 1, 1)
             # the weight gradients: one grouped launch pair after the chain, written into the flat gradient vector
             with ops.deferred_wgrad(grad_dst=getattr(self, "_grad_dst", None)):
                 eval_q_tot.backward(gy)
-            assert ops._PENDING_TD is None, "the fused mixer's backward did not take the TD loss"
         else:
             loss, eval_mean, target_mean = ops.td_loss_full(eval_q_tot, target_q_tot, st["reward"], st["terminated"],
                                                             st["filled"], self.args.gamma, T - 1, 1)
@@ -510,7 +507,15 @@ class QMixLearner:
         self._g_buffer, self._g_B, self._g_T = buffer, int(batch_size), int(buffer.episode_limit)
         # static observations in every stored episode (see _forward_backward_full): baked into the captured launches
         self._g_obs_static = bool(getattr(buffer, "obs_static", False)) and os.environ.get("MACJD_LEARNER_STATIC_OBS", "1") != "0"
-        self._g_actor_in_scan = os.environ.get("MACJD_ACTOR_IN_SCAN", "1") != "0"
+        # the actor rows ride in the scan launch where the one-launch Double-DQN step consumes them per sequence (the
+        # benchmark's sizes); sizes without that launch keep the actor chain as its own launch on the origin stream — the
+        # arrangement their graphs were validated with (the other one, with the rows expanded behind the join for the
+        # two-launch form, showed host faults inside hipGraphLaunch in two of ~15 full test runs)
+        self._g_actor_in_scan = os.environ.get("MACJD_ACTOR_IN_SCAN", "1") != "0" and \
+            (os.environ.get("MACJD_ACTOR_IN_SCAN") == "1" or
+             (os.environ.get("MACJD_FUSED_DOUBLEQ", "1") != "0" and
+              ops.qhead_double_q_fused_supported(self._flat_param if self._flat_param is not None else buffer.buffers["obs"],
+                                                 int(self.args.rnn_hidden_dim), int(self.n_actions))))
         self._g_scan_from_ring = self._g_obs_static and os.environ.get("MACJD_SCAN_FROM_RING", "1") != "0" \
             and int(buffer.buffers["obs"].shape[-1]) <= 3 * int(self.args.rnn_hidden_dim)
         self._g_idx = torch.zeros(self._g_B, dtype=torch.int64, device=self.device)

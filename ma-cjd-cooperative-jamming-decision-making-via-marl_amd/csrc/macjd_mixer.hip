@@ -252,18 +252,8 @@ __global__ void __launch_bounds__(256) mixer_fused_forward_kernel(const macjd_mi
 }
 
 // Backward (see the header): recompute the second layers from `act`, tail gradients, transposed second layers.
-// TD = the TD loss of the learner rides in this launch (macjd_mixer_fused_backward_td): io.gy is not read, the
-// gradient dL/dQ_tot of row m = (b, t) is formed from the loss's own inputs with td_loss_kernel's expressions —
-// scale * mask * (y - (r + gamma (1 - term) tq)), scale = 2 / sum(mask), zero for t >= Tm1 — after every workgroup has
-// summed the batch's mask for itself (B * Tm1 bytes; exact whatever the order), and workgroup 0 also writes the four
-// logged scalars, accumulated in the order of td_loss_kernel's 1024 threads (bit-identical statistics).
-__device__ __forceinline__ float mxb_wave_sum(float x) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
-    return x;
-}
-template <int J, bool TD = false>
-__global__ void __launch_bounds__(256) mixer_fused_backward_kernel(const macjd_mixerf_io io, const macjd_tdloss_io td) {
+template <int J>
+__global__ void __launch_bounds__(256) mixer_fused_backward_kernel(const macjd_mixerf_io io) {
     constexpr int LDG = J * MX_EM + 8;      // pitch of g_w1raw in LDS (= 8 mod 16)
     constexpr int LDF = MX_EM + 8;
     constexpr int KQ1 = J * MX_EM / 16;     // quads of the transposed hyper_w_1.2 product
@@ -314,106 +304,13 @@ __global__ void __launch_bounds__(256) mixer_fused_backward_kernel(const macjd_m
 #pragma unroll
     for (int i = 0; i < 4; ++i) wvo[i] = io.wV2[(threadIdx.x + 256 * i) & (MX_EM - 1)];   // for the V head's outer product
     const float bV2 = io.bV2[0];
-    // TD: every load of this block is issued in batches with clamped indices (a loop whose body loads and then adds
-    // waits for memory once per iteration: the first version of this block cost the launch 6 us)
-    float td_scale = 0.0f;
-    float td_pre[5] = {0.f, 0.f, 0.f, 0.f, 0.f};   // un-scaled mask * (y - target) of rows m0 + li and m0 + 4 g + r
-    if constexpr (TD) {
-        __shared__ float s_td[4][16], s_tot[4];
-        const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
-        const int Mtd = td.B * td.Tm1, cols = (int)td.gy_cols;
-        auto td_err = [&](const int b, const int t, float& y, float& target, float& mk) {   // loads of item (b, t)
-            const float term = td.terminated[b * td.t_sb + t * td.t_st] ? 1.0f : 0.0f;
-            mk = td.filled[b * td.f_sb + t * td.f_st] ? 1.0f : 0.0f;
-            y = td.y[b * td.y_sb + t];
-            target = td.reward[b * td.r_sb + t * td.r_st] + td.gamma * (1.0f - term) * td.tq[b * td.tq_sb + t];
-        };
-        // (1) the rows this thread needs the gradient of
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int64_t m = (k == 0) ? m0 + li : m0 + 4 * g + (k - 1);
-            const int64_t mc = m < io.M ? m : io.M - 1;
-            const int b = (int)(mc / cols), t = (int)(mc - (int64_t)b * cols);
-            float y, target, mk;
-            td_err(b, t < td.Tm1 ? t : td.Tm1 - 1, y, target, mk);
-            td_pre[k] = (t < td.Tm1) ? mk * (y - target) : 0.0f;
-        }
-        // (2) this thread's share of the batch's mask, 16 bytes in flight per pass
-        float sm = 0.0f;
-        for (int base = 0; base < Mtd; base += 4096) {
-            uint8_t f[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int i = base + u * 256 + (int)threadIdx.x, ic = i < Mtd ? i : Mtd - 1;
-                const int b = ic / td.Tm1, t = ic - b * td.Tm1;
-                f[u] = td.filled[b * td.f_sb + t * td.f_st];
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) sm += (base + u * 256 + (int)threadIdx.x < Mtd && f[u]) ? 1.0f : 0.0f;
-        }
-        sm = mxb_wave_sum(sm);
-        if (lane_ == 0) s_td[0][wave_] = sm;
-        __syncthreads();
-        const float tot_m = (s_td[0][0] + s_td[0][1]) + (s_td[0][2] + s_td[0][3]);   // small integers: exact
-        td_scale = 2.0f / tot_m;
-        if (blockIdx.x == 0) {
-            // the logged scalars, in td_loss_kernel's order: thread v of its 1024 accumulates items v, v + 1024, ...;
-            // here thread tid plays v = tid + 256 k, k = 0..3, with separate accumulators (four passes' loads in flight)
-            __syncthreads();
-            float a_e2[4] = {0.f, 0.f, 0.f, 0.f}, a_y[4] = {0.f, 0.f, 0.f, 0.f}, a_t[4] = {0.f, 0.f, 0.f, 0.f},
-                  a_m[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int base = 0; base < Mtd; base += 4096) {
-                float yv[4][4], tv[4][4], mv[4][4];
-#pragma unroll
-                for (int p = 0; p < 4; ++p)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int i = base + 1024 * p + 256 * k + (int)threadIdx.x, ic = i < Mtd ? i : Mtd - 1;
-                        td_err(ic / td.Tm1, ic - (ic / td.Tm1) * td.Tm1, yv[p][k], tv[p][k], mv[p][k]);
-                    }
-#pragma unroll
-                for (int p = 0; p < 4; ++p)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (base + 1024 * p + 256 * k + (int)threadIdx.x < Mtd) {
-                            const float e = (yv[p][k] - tv[p][k]) * mv[p][k];
-                            a_m[k] += mv[p][k]; a_e2[k] += e * e; a_y[k] += yv[p][k]; a_t[k] += tv[p][k];
-                        }
-                    }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float q4[4] = {mxb_wave_sum(a_m[k]), mxb_wave_sum(a_e2[k]), mxb_wave_sum(a_y[k]), mxb_wave_sum(a_t[k])};
-                if (lane_ == 0) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) s_td[c][wave_ + 4 * k] = q4[c];
-                }
-            }
-            __syncthreads();
-            if (wave_ == 0) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float t = (lane_ < 16) ? s_td[c][lane_] : 0.0f;
-                    t = mxb_wave_sum(t);
-                    if (lane_ == 0) s_tot[c] = t;
-                }
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                td.stats[0] = s_tot[1] / s_tot[0];                                   // qmix.py:194
-                td.stats[1] = s_tot[2] / (float)Mtd;
-                td.stats[2] = s_tot[3] / (float)Mtd;
-                td.stats[3] = s_tot[0];
-            }
-        }
-    }
-    const float gy_li = TD ? td_scale * td_pre[0] : io.gy[(m0 + li < io.M) ? m0 + li : io.M - 1];
+    const float gy_li = io.gy[(m0 + li < io.M) ? m0 + li : io.M - 1];
     float qv[4][J], gyv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int64_t m = m0 + 4 * g + r;
         const int64_t mc = m < io.M ? m : io.M - 1;   // clamped (no branch around a load); rows past M are never stored
-        gyv[r] = TD ? td_scale * td_pre[1 + r] : io.gy[mc];
+        gyv[r] = io.gy[mc];
 #pragma unroll
         for (int j = 0; j < J; ++j) qv[r][j] = io.q[mc * J + j];
     }
@@ -523,7 +420,7 @@ __global__ void __launch_bounds__(256) mixer_fused_backward_kernel(const macjd_m
     }
 }
 
-static int mixerf_check(const macjd_mixerf_io* io, bool backward, bool gy_from_td = false) {
+static int mixerf_check(const macjd_mixerf_io* io, bool backward) {
     if (!io) return set_err(MACJD_EINVAL, "%s", "macjd_mixer_fused: NULL io");
     if (!macjd_mixer_fused_supported(io->J, io->S, io->Hh, io->Em))
         return set_err(MACJD_EUNSUPPORTED, "%s", "macjd_mixer_fused: unsupported J / S / Hh / Em (see include/macjd_nets.h)");
@@ -534,7 +431,7 @@ static int mixerf_check(const macjd_mixerf_io* io, bool backward, bool gy_from_t
             return set_err(MACJD_EINVAL, "%s", "macjd_mixer_fused_forward: NULL input / output or bad s_ld");
         if (io->save && (!io->sn || !io->xhat || !io->act))
             return set_err(MACJD_EINVAL, "%s", "macjd_mixer_fused_forward: save needs sn / xhat / act");
-    } else if (!io->act || (!io->gy && !gy_from_td) || !io->gq || !io->gout1 || !io->g_w1raw || !io->g_wfraw || !io->g_v) {
+    } else if (!io->act || !io->gy || !io->gq || !io->gout1 || !io->g_w1raw || !io->g_wfraw || !io->g_v) {
         return set_err(MACJD_EINVAL, "%s", "macjd_mixer_fused_backward: NULL input / output");
     }
     if (((uintptr_t)io->act) & 15)   // (weights may sit anywhere in a flat parameter vector: their fragment loads assume 4 bytes)
@@ -577,29 +474,10 @@ extern "C" int macjd_mixer_fused_backward(const macjd_mixerf_io* io, void* hip_s
     if (io->M == 0) return MACJD_OK;
     const dim3 grid((unsigned)((io->M + 15) / 16)), block(256);
     hipStream_t s = (hipStream_t)hip_stream;
-    const macjd_tdloss_io none{};
-    if (io->J == 2) hipLaunchKernelGGL((mixer_fused_backward_kernel<2>), grid, block, 0, s, *io, none);
-    else if (io->J == 3) hipLaunchKernelGGL((mixer_fused_backward_kernel<3>), grid, block, 0, s, *io, none);
-    else hipLaunchKernelGGL((mixer_fused_backward_kernel<6>), grid, block, 0, s, *io, none);
+    if (io->J == 2) hipLaunchKernelGGL((mixer_fused_backward_kernel<2>), grid, block, 0, s, *io);
+    else if (io->J == 3) hipLaunchKernelGGL((mixer_fused_backward_kernel<3>), grid, block, 0, s, *io);
+    else hipLaunchKernelGGL((mixer_fused_backward_kernel<6>), grid, block, 0, s, *io);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_mixer_fused_backward: %s", hipGetErrorString(err));
-    return MACJD_OK;
-}
-
-extern "C" int macjd_mixer_fused_backward_td(const macjd_mixerf_io* io, const macjd_tdloss_io* td, void* hip_stream) {
-    using namespace macjd;
-    const int rc = mixerf_check(io, true, true);
-    if (rc != MACJD_OK) return rc;
-    if (!td || td->B < 1 || td->Tm1 < 1 || !td->y || !td->tq || !td->reward || !td->terminated || !td->filled || !td->stats)
-        return set_err(MACJD_EINVAL, "%s", "macjd_mixer_fused_backward_td: bad TD-loss argument");
-    if (td->gy_cols < td->Tm1 || (int64_t)td->B * td->gy_cols != io->M || td->y_sb < td->Tm1 || td->tq_sb < td->Tm1)
-        return set_err(MACJD_EINVAL, "%s", "macjd_mixer_fused_backward_td: rows must be B x gy_cols with gy_cols >= Tm1");
-    const dim3 grid((unsigned)((io->M + 15) / 16)), block(256);
-    hipStream_t s = (hipStream_t)hip_stream;
-    if (io->J == 2) hipLaunchKernelGGL((mixer_fused_backward_kernel<2, true>), grid, block, 0, s, *io, *td);
-    else if (io->J == 3) hipLaunchKernelGGL((mixer_fused_backward_kernel<3, true>), grid, block, 0, s, *io, *td);
-    else hipLaunchKernelGGL((mixer_fused_backward_kernel<6, true>), grid, block, 0, s, *io, *td);
-    const hipError_t err = hipGetLastError();
-    if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_mixer_fused_backward_td: %s", hipGetErrorString(err));
     return MACJD_OK;
 }

@@ -51,3 +51,4 @@ def _quiet_point_for_graph_teardown(request):
         gc.enable()
         gc.collect()
         torch.cuda.synchronize()
+        torch.cuda.empty_cache()   # the finished test's graph pools and cached blocks go back to the driver now

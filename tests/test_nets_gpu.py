@@ -1786,44 +1786,3 @@ def test_relu_backward_operand_formed_inside_the_weight_gradient_kernel(N, K, Hd
     (torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(x, w1, b1)), w2, b2) * up).sum().backward()
     for t, c in zip(ps, got):
         np.testing.assert_allclose(c.cpu().numpy(), t.grad.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(t.grad.abs().max()))
-
-
-@pytest.mark.parametrize("B,T1", [(32, 101), (3, 7)])
-def test_td_loss_inside_the_fused_mixer_backward(B, T1):
-    """macjd_mixer_fused_backward_td: the TD loss, its four logged scalars and dL/dQ_tot computed inside the eval mixer's
-    backward launch == the separate TD-loss launch followed by the plain backward launch — statistics and every gradient
-    bitwise (the in-kernel sums follow td_loss_kernel's order)."""
-    from macjd_amd import ops
-    from macjd_amd.core.networks import QMixer
-    g, d = load("3j4r_h64")
-    args = _gpu_args(d)
-    torch.manual_seed(4)
-    with quiet():
-        mixer = QMixer(args).to(DEV)
-    mixer.load_state_dict(sd_from(g, "g5_mixer0."))
-    J, S = d["J"], d["S"]
-    gen = torch.Generator().manual_seed(B)
-    state = torch.randn(B, T1, S, generator=gen).to(DEV)
-    q0 = torch.randn(B, T1, J, generator=gen).to(DEV)
-    tq = torch.randn(B, T1, 1, generator=gen).to(DEV)
-    reward = torch.randn(B, T1 - 1, 1, generator=gen).to(DEV)
-    term = (torch.rand(B, T1 - 1, 1, generator=gen) < 0.1).to(DEV)
-    filled = (torch.rand(B, T1 - 1, 1, generator=gen) < 0.9).to(DEV)
-    assert mixer.fused_available(state)
-
-    def run(in_mixer):
-        q = q0.clone().requires_grad_(True)
-        for p_ in mixer.parameters():
-            p_.grad = None
-        y = mixer(q, state)
-        assert ops.fused_mixer_backward_will_run(y)
-        f = ops.td_loss_in_mixer_backward if in_mixer else ops.td_loss_and_grad
-        loss, my, mt, gy, stats = f(y, tq, reward, term, filled, 0.99, T1 - 2, 1)
-        y.backward(gy)
-        assert ops._PENDING_TD is None
-        return [stats.clone(), q.grad.clone()] + [p_.grad.clone() for p_ in mixer.parameters()]
-
-    ref, got = run(False), run(True)
-    assert float(ref[0][3]) > 0 and torch.isfinite(ref[0]).all()
-    for a, c in zip(ref, got):
-        assert torch.equal(a, c)
