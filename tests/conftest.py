@@ -28,3 +28,22 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionstart(session):
+    """HIP graphs captured by a test stay alive until the session ends.  Destroying a graph (and releasing its private
+    memory pool) while later tests capture and replay their own has produced host faults inside hipGraphLaunch on this
+    ROCm stack — intermittently with Python's own collector, deterministically when a fixture forced the collection
+    after every test.  A training process never destroys its graphs mid-run; the test session now does not either."""
+    if not _has_gpu():
+        return
+    import torch
+    keep = []
+    orig = torch.cuda.CUDAGraph.capture_end
+
+    def capture_end(self):
+        orig(self)
+        keep.append(self)
+
+    torch.cuda.CUDAGraph.capture_end = capture_end
+    session.config._macjd_graphs_kept = keep
