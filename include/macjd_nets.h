@@ -263,6 +263,34 @@ typedef struct macjd_qinput_io {
 int macjd_qhead_input(const macjd_qinput_io* io, void* hip_stream);
 
 /*
+ * Q-value of the TAKEN action for n rows — RNNAgent.get_q_value_for_action (reference core/networks.py:131-180: one_hot,
+ * cat, Linear, ReLU, Linear), the only differentiable path of the learner's loss into the agent (core/qmix.py:161-184) —
+ * as ONE launch instead of macjd_qhead_input + a library GEMM with bias / ReLU epilogue + macjd_rowdot:
+ *   x[n, :]   = [h[n, 0..H-1], onehot_A(idx[n]), P[n]]                   (written: the backward's weight-gradient operand)
+ *   act[n, u] = ReLU(sum_k W1[u, k] h[n, k] + b1[u] + W1[u, H + idx[n]] + W1[u, H + A] P[n])   (written: saved for backward)
+ *   q[n]      = sum_u w2[u] act[n, u] + b2
+ * The H x H product runs on exact-f32 MFMA (32 rows per workgroup, wave w owns hidden units [16w, 16w+16), W1's h-columns
+ * as register fragments); the one-hot / power columns of W1 are a gather from LDS.  H = 64 (= rows of W1), A <= 64,
+ * h rows 16-byte aligned.  idx outside [0, A): empty one-hot block.  Differs from the three-launch form by the summation
+ * order of the first layer (~1e-7 relative).
+ */
+typedef struct macjd_qtaken_io {
+    int64_t n_rows;
+    int32_t H, A;
+    const float* h;   int64_t h_ld;                       /* [n_rows, H] */
+    const void* idx;  int32_t idx_elem_size, reserved;    /* [n_rows] int32 (4) or int64 (8), contiguous */
+    const float* P;                                       /* [n_rows] contiguous */
+    const float* W1;  int64_t w1_ld;                      /* fc2_q_head.0.weight [H, H + A + 1] */
+    const float* b1;  const float* w2;  const float* b2;  /* [H], fc2_q_head.2.weight [H], .bias [1] or NULL */
+    float* x;         int64_t x_ld;                       /* [n_rows, H + A + 1] out (may be NULL) */
+    float* act;       int64_t act_ld;                     /* [n_rows, H] out */
+    float* q;                                             /* [n_rows] out */
+} macjd_qtaken_io;
+
+int macjd_qhead_taken_supported(int32_t H, int32_t A);   /* 1 / 0 */
+int macjd_qhead_taken(const macjd_qtaken_io* io, void* hip_stream);
+
+/*
  * LayerNorm forward over the last dimension (QMixer.state_norm, reference core/networks.py:215,270):
  *   mean = sum(x)/S, var = sum((x-mean)^2)/S (biased, two-pass), rstd = rsqrt(var + eps), y = (x-mean) rstd gamma + beta.
  * mean / rstd [M] are saved for torch's native_layer_norm_backward.  S <= 1024.

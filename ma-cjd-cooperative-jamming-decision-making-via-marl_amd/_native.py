@@ -28,7 +28,7 @@ EXPORTS = [
     "macjd_linear_wgrad", "macjd_linear_wgrad_workspace_floats", "macjd_linear_wgrad_many", "macjd_qhead_input", "macjd_layernorm_forward", "macjd_layernorm_param_grad", "macjd_gru_gates", "macjd_rowdot", "macjd_splitrelu_backward",
     "macjd_mixer_fused_supported", "macjd_mixer_fused_forward", "macjd_mixer_fused_backward",
     "macjd_agent_episode_supported", "macjd_agent_episode", "macjd_env_step_many", "macjd_env_step_many_timed",
-    "macjd_qhead_double_q_supported", "macjd_qhead_double_q",
+    "macjd_qhead_double_q_supported", "macjd_qhead_double_q", "macjd_qhead_taken_supported", "macjd_qhead_taken",
 ]
 
 
@@ -243,6 +243,21 @@ class AdamIO(ctypes.Structure):
     ]
 
 
+class QtakenIO(ctypes.Structure):
+    """ctypes mirror of ``macjd_qtaken_io`` (include/macjd_nets.h)."""
+    _fields_ = [
+        ("n_rows", ctypes.c_int64), ("H", ctypes.c_int32), ("A", ctypes.c_int32),
+        ("h", ctypes.c_void_p), ("h_ld", ctypes.c_int64),
+        ("idx", ctypes.c_void_p), ("idx_elem_size", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("P", ctypes.c_void_p),
+        ("W1", ctypes.c_void_p), ("w1_ld", ctypes.c_int64),
+        ("b1", ctypes.c_void_p), ("w2", ctypes.c_void_p), ("b2", ctypes.c_void_p),
+        ("x", ctypes.c_void_p), ("x_ld", ctypes.c_int64),
+        ("act", ctypes.c_void_p), ("act_ld", ctypes.c_int64),
+        ("q", ctypes.c_void_p),
+    ]
+
+
 class SamplerIO(ctypes.Structure):
     """ctypes mirror of ``macjd_sampler_io`` (include/macjd_nets.h)."""
     _fields_ = [
@@ -330,6 +345,10 @@ def load() -> ctypes.CDLL:
     for name in ("macjd_mixer_fused_forward", "macjd_mixer_fused_backward"):
         getattr(lib, name).restype = ctypes.c_int
         getattr(lib, name).argtypes = [ctypes.POINTER(MixerFusedIO), ctypes.c_void_p]
+    lib.macjd_qhead_taken_supported.restype = ctypes.c_int
+    lib.macjd_qhead_taken_supported.argtypes = [ctypes.c_int32, ctypes.c_int32]
+    lib.macjd_qhead_taken.restype = ctypes.c_int
+    lib.macjd_qhead_taken.argtypes = [ctypes.POINTER(QtakenIO), ctypes.c_void_p]
     lib.macjd_qhead_input.restype = ctypes.c_int
     lib.macjd_qhead_input.argtypes = [ctypes.POINTER(QinputIO), ctypes.c_void_p]
     lib.macjd_layernorm_forward.restype = ctypes.c_int

@@ -164,6 +164,9 @@ class RNNAgent(nn.Module):
         l1, l2 = self.fc2_q_head[0], self.fc2_q_head[2]
         # cat([h, onehot(a), P]) -> Linear -> ReLU -> Linear, exactly the reference's formulation (networks.py:171-176);
         # the one-hot is a compare + cast (any integer dtype), the Linears use the split-K weight gradient on a HIP device
+        if ops.qhead_taken_supported(hidden_state, l1.weight, l2.weight, self.n_actions):
+            # the learner's case on a HIP device: input rows, first layer + ReLU and the second layer's dot in ONE launch
+            return ops.qhead_taken(hidden_state, idx, continuous_param, l1.weight, l1.bias, l2.weight, l2.bias, self.n_actions)
         q_head_input = ops.qhead_input(hidden_state, idx, continuous_param, self.n_actions)   # [h, onehot(a), P]
         return ops.linear_relu_dot(q_head_input, l1.weight, l1.bias, l2.weight, l2.bias)
 

@@ -384,7 +384,112 @@ __global__ void __launch_bounds__(256) qhead_double_q_kernel(const macjd_doubleq
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Taken-action Q-values of the learner in one launch (include/macjd_nets.h, macjd_qtaken_io).
+constexpr int QT_TILES = 2;       // 16-row MFMA tiles per workgroup: 32 rows (303 workgroups for the update's 9 696 rows)
+constexpr int QT_AMAX = 64;
+
+__global__ void __launch_bounds__(256) qhead_taken_kernel(const macjd_qtaken_io io) {
+    __shared__ __attribute__((aligned(16))) float Hl[QT_TILES][16 * EP_LD];   // h rows of the workgroup
+    __shared__ float Wc[(QT_AMAX + 1) * EP_H];                                // W1[u][H + a] at [a][u], a = A: power column
+    __shared__ float Qp[4][QT_TILES * 16];                                    // per-wave partial sums of q
+    __shared__ int s_idx[QT_TILES * 16];
+    __shared__ float s_P[QT_TILES * 16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    const int A = io.A, W = EP_H + A + 1;
+    const int64_t r0 = (int64_t)blockIdx.x * (16 * QT_TILES);
+    // weight fragments of this wave's 16 units (B operands), bias, second-layer weight
+    f32x4 Bq[EP_KQ];
+#pragma unroll
+    for (int Q = 0; Q < EP_KQ; ++Q)
+        Bq[Q] = *reinterpret_cast<const f32x4_u*>(io.W1 + (int64_t)(16 * wave + li) * io.w1_ld + 16 * Q + 4 * g);
+    const int u = 16 * wave + li;
+    const float b1u = io.b1[u], w2u = io.w2[u];
+    // ---- stage: h rows (float4), the action / power columns of W1, the rows' action index and power ----
+    for (int i = threadIdx.x; i < QT_TILES * 16 * (EP_H / 4); i += 256) {
+        const int row = i / (EP_H / 4), c4 = i - row * (EP_H / 4);
+        const int64_t rc = (r0 + row < io.n_rows) ? r0 + row : io.n_rows - 1;   // clamped: rows past n are computed, never stored
+        *reinterpret_cast<f32x4*>(&Hl[row >> 4][(row & 15) * EP_LD + 4 * c4]) =
+            *reinterpret_cast<const f32x4*>(io.h + rc * io.h_ld + 4 * c4);
+    }
+    for (int i = threadIdx.x; i < (A + 1) * EP_H; i += 256) {
+        const int a = i / EP_H, uu = i - a * EP_H;
+        Wc[i] = io.W1[(int64_t)uu * io.w1_ld + EP_H + a];
+    }
+    if (threadIdx.x < QT_TILES * 16) {
+        const int64_t rc = (r0 + threadIdx.x < io.n_rows) ? r0 + threadIdx.x : io.n_rows - 1;
+        const int64_t a = (io.idx_elem_size == 8) ? ((const int64_t*)io.idx)[rc] : (int64_t)((const int32_t*)io.idx)[rc];
+        s_idx[threadIdx.x] = (a >= 0 && a < A) ? (int)a : -1;
+        s_P[threadIdx.x] = io.P[rc];
+    }
+    __syncthreads();
+    // ---- the Q-head's input rows [h, onehot(a), P] (the backward's weight-gradient operand) ----
+    if (io.x) {
+        for (int i = threadIdx.x; i < QT_TILES * 16 * W; i += 256) {
+            const int row = i / W, c = i - row * W;
+            if (r0 + row < io.n_rows) {
+                const float v = (c < EP_H) ? Hl[row >> 4][(row & 15) * EP_LD + c]
+                                           : (c < EP_H + A) ? ((s_idx[row] == c - EP_H) ? 1.0f : 0.0f) : s_P[row];
+                io.x[(r0 + row) * io.x_ld + c] = v;
+            }
+        }
+    }
+    // ---- base = W1[:, :H] h on MFMA, then the one-hot / power columns, bias, ReLU, and the second layer's dot ----
+#pragma unroll
+    for (int tile = 0; tile < QT_TILES; ++tile) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int Q = 0; Q < EP_KQ; ++Q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&Hl[tile][li * EP_LD + 16 * Q + 4 * g]);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], Bq[Q][jj], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {   // C layout: this lane holds rows 4g + r of column (unit) li
+            const int row = 16 * tile + 4 * g + r;
+            const int a = s_idx[row];
+            const float v = ((acc[r] + b1u) + (a >= 0 ? Wc[a * EP_H + u] : 0.0f)) + Wc[A * EP_H + u] * s_P[row];
+            const float act = v > 0.0f ? v : 0.0f;
+            if (r0 + row < io.n_rows) io.act[(r0 + row) * io.act_ld + u] = act;
+            float qp = act * w2u;       // sum over the wave's 16 units: the 16 lanes li of this row group
+            qp += __shfl_xor(qp, 1, 64);
+            qp += __shfl_xor(qp, 2, 64);
+            qp += __shfl_xor(qp, 4, 64);
+            qp += __shfl_xor(qp, 8, 64);
+            if (li == 0) Qp[wave][row] = qp;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < QT_TILES * 16 && r0 + threadIdx.x < io.n_rows) {
+        const int row = threadIdx.x;
+        io.q[r0 + row] = ((Qp[0][row] + Qp[1][row]) + (Qp[2][row] + Qp[3][row])) + (io.b2 ? io.b2[0] : 0.0f);
+    }
+}
+
 }  // namespace macjd
+
+extern "C" int macjd_qhead_taken_supported(int32_t H, int32_t A) {
+    return (H == macjd::EP_H && A >= 1 && A <= macjd::QT_AMAX) ? 1 : 0;
+}
+
+extern "C" int macjd_qhead_taken(const macjd_qtaken_io* io, void* hip_stream) {
+    using namespace macjd;
+    if (!io) return set_err(MACJD_EINVAL, "%s", "macjd_qhead_taken: NULL io");
+    if (!macjd_qhead_taken_supported(io->H, io->A)) return set_err(MACJD_EUNSUPPORTED, "%s", "macjd_qhead_taken: unsupported H / A");
+    if (io->n_rows < 0 || !io->h || !io->idx || !io->P || !io->W1 || !io->b1 || !io->w2 || !io->act || !io->q)
+        return set_err(MACJD_EINVAL, "%s", "macjd_qhead_taken: bad n_rows or NULL pointer");
+    if ((io->idx_elem_size != 4 && io->idx_elem_size != 8) || io->h_ld < io->H || (io->h_ld & 3) || (((uintptr_t)io->h) & 15) ||
+        io->w1_ld < io->H + io->A + 1 || io->act_ld < io->H || (io->x && io->x_ld < io->H + io->A + 1))
+        return set_err(MACJD_EINVAL, "%s", "macjd_qhead_taken: bad stride / alignment / index size");
+    if (io->n_rows == 0) return MACJD_OK;
+    const dim3 grid((unsigned)((io->n_rows + 16 * QT_TILES - 1) / (16 * QT_TILES)));
+    hipLaunchKernelGGL(qhead_taken_kernel, grid, dim3(256), 0, (hipStream_t)hip_stream, *io);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_qhead_taken: %s", hipGetErrorString(err));
+    return MACJD_OK;
+}
 
 extern "C" int macjd_qhead_double_q_supported(int32_t H, int32_t A) {
     return (H == macjd::EP_H) && (A == 5 || A == 9 || A == 17);

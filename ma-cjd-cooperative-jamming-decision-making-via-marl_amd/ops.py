@@ -1346,6 +1346,68 @@ class _LinearReluRowDot(torch.autograd.Function):
         return gx, gW1, gb1, gW2, (gb2 if ctx.has_b2 else None)
 
 
+class _QheadTaken(torch.autograd.Function):
+    """q = Q-head([h, onehot(idx), P]) for the TAKEN action (reference core/networks.py:131-180) as ONE forward launch
+    (macjd_qhead_taken: input rows, first layer on MFMA + ReLU, second layer's dot); the backward is
+    ``_LinearReluRowDot``'s on the saved input rows and activations (h / idx / P are data: no input gradient)."""
+
+    @staticmethod
+    def forward(ctx, h, idx, P, w1, b1, w2, b2, n_actions):
+        lib = _native.load()
+        n, H = h.shape
+        hc = h.detach()
+        if hc.dtype != torch.float32 or hc.stride(1) != 1 or (hc.stride(0) & 3) or (hc.data_ptr() & 15):
+            hc = hc.float().contiguous()
+        Pc = P.detach().float().reshape(n).contiguous()
+        ic = idx.detach().reshape(n)
+        if ic.dtype not in (torch.int32, torch.int64):
+            ic = ic.to(torch.int64)
+        ic = ic.contiguous()
+        w1c, b1c, w2c = _f32c(w1.detach()), _f32c(b1.detach()), _f32c(w2.detach()).reshape(-1)
+        x = torch.empty((n, H + n_actions + 1), dtype=torch.float32, device=h.device)
+        act = torch.empty((n, H), dtype=torch.float32, device=h.device)
+        q = torch.empty((n, 1), dtype=torch.float32, device=h.device)
+        io = _native.QtakenIO()
+        io.n_rows, io.H, io.A = n, H, int(n_actions)
+        io.h, io.h_ld, io.idx, io.idx_elem_size, io.P = hc.data_ptr(), hc.stride(0), ic.data_ptr(), ic.element_size(), Pc.data_ptr()
+        io.W1, io.w1_ld, io.b1, io.w2 = w1c.data_ptr(), w1c.stride(0), b1c.data_ptr(), w2c.data_ptr()
+        io.b2 = _f32c(b2.detach()).data_ptr() if b2 is not None else None
+        io.x, io.x_ld, io.act, io.act_ld, io.q = x.data_ptr(), x.stride(0), act.data_ptr(), act.stride(0), q.data_ptr()
+        with torch.cuda.device(h.device):
+            _native.check(lib.macjd_qhead_taken(ctypes.byref(io), _stream(h)), "macjd_qhead_taken")
+        ctx.save_for_backward(x, w1, act, w2)
+        ctx.has_b2, ctx.b1_key, ctx.b2_key = b2 is not None, grad_key(b1), grad_key(b2)
+        return q
+
+    @staticmethod
+    def backward(ctx, gq):
+        x, w1, y, w2 = ctx.saved_tensors
+        nd = ctx.needs_input_grad
+        gW1 = gb1 = gW2 = gb2 = None
+        if nd[3] or nd[4]:   # the first layer's operand gq w2 masked by the ReLU is formed inside the weight-gradient kernel
+            gW1, gb1 = linear_wgrad(y, x, want_bias=True, w_key=grad_key(w1), b_key=ctx.b1_key, need=(nd[3], nd[4]),
+                                    outer=(gq, w2))
+        if nd[5] or (ctx.has_b2 and nd[6]):
+            gW2, gb2 = linear_wgrad(gq.reshape(-1, 1), y, want_bias=ctx.has_b2, w_key=grad_key(w2), b_key=ctx.b2_key,
+                                    need=(nd[5], ctx.has_b2 and nd[6]))
+        return None, None, None, gW1, gb1, gW2, (gb2 if ctx.has_b2 else None), None
+
+
+def qhead_taken_supported(h, w1, w2, n_actions: int) -> bool:
+    """The one-launch form of the taken-action Q-head applies: HIP device, float32, H = 64 hidden units in both the GRU and
+    the Q-head, enough rows for the split-K weight gradients, autograd on (it exists for the learner's forward)."""
+    return (h.is_cuda and h.dim() == 2 and h.dtype == torch.float32 and w1.dtype == torch.float32 and not torch.is_autocast_enabled()
+            and h.shape[0] >= 1024 and w1.shape[0] == h.shape[1] and w1.shape[1] == h.shape[1] + n_actions + 1
+            and w2.shape[0] == 1 and torch.is_grad_enabled() and (w1.requires_grad or w2.requires_grad) and not h.requires_grad
+            and os.environ.get("MACJD_QHEAD_TAKEN", "1") != "0"
+            and bool(_native.load().macjd_qhead_taken_supported(int(h.shape[1]), int(n_actions))))
+
+
+def qhead_taken(h, idx, P, w1, b1, w2, b2, n_actions: int):
+    """Q(h, idx, P) [n, 1] through ``_QheadTaken`` (callers check ``qhead_taken_supported``)."""
+    return _QheadTaken.apply(h, idx, P, w1, b1, w2, b2, int(n_actions))
+
+
 def linear_relu_dot(x, w1, b1, w2, b2):
     """F.linear(relu(F.linear(x, w1, b1)), w2, b2) for a one-output second layer; one autograd node on a HIP device."""
     if (_fused_relu_ok(x, w1, b1) and torch.is_grad_enabled() and (w1.requires_grad or w2.requires_grad or x.requires_grad)

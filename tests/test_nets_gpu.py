@@ -1786,3 +1786,54 @@ def test_relu_backward_operand_formed_inside_the_weight_gradient_kernel(N, K, Hd
     (torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(x, w1, b1)), w2, b2) * up).sum().backward()
     for t, c in zip(ps, got):
         np.testing.assert_allclose(c.cpu().numpy(), t.grad.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(t.grad.abs().max()))
+
+
+@pytest.mark.parametrize("n,A,idt", [(9696, 9, torch.int32), (1037, 33, torch.int64), (2048, 5, torch.int64)])
+def test_taken_action_qhead_in_one_launch(n, A, idt, monkeypatch):
+    """macjd_qhead_taken (input rows + first layer on MFMA + ReLU + second layer's dot, one launch) == the three-launch
+    form (macjd_qhead_input, library GEMM with bias / ReLU epilogue, macjd_rowdot): the input rows bitwise, Q-values and
+    activations to 1e-5 (the first layer's summation order differs), all four parameter gradients to the weight-gradient
+    tolerance; out-of-range action indices give an empty one-hot block; ragged row counts."""
+    from macjd_amd import ops
+    H = 64
+    g = torch.Generator().manual_seed(n + A)
+    h = torch.randn(n, H, generator=g).to(DEV)
+    idx = torch.randint(-1, A + 1, (n,), generator=g).to(idt).to(DEV)     # incl. -1 and A: empty one-hot
+    P = torch.rand(n, 1, generator=g).to(DEV)
+    w1 = (torch.randn(H, H + A + 1, generator=g) * 0.2).to(DEV).requires_grad_(True)
+    b1 = torch.randn(H, generator=g).to(DEV).requires_grad_(True)
+    w2 = torch.randn(1, H, generator=g).to(DEV).requires_grad_(True)
+    b2 = torch.randn(1, generator=g).to(DEV).requires_grad_(True)
+    up = torch.randn(n, 1, generator=g).to(DEV)
+    ps = (w1, b1, w2, b2)
+    assert ops.qhead_taken_supported(h, w1, w2, A)
+
+    def run(fused):
+        for t in ps:
+            t.grad = None
+        if fused:
+            q = ops.qhead_taken(h, idx, P, w1, b1, w2, b2, A)
+            assert type(q.grad_fn).__name__.startswith("_QheadTaken")
+            x, act = q.grad_fn.saved_tensors[0], q.grad_fn.saved_tensors[2]
+        else:
+            x = ops.qhead_input(h, idx, P, A)
+            q = ops.linear_relu_dot(x, w1, b1, w2, b2)
+            act = q.grad_fn.saved_tensors[2]
+        with ops.deferred_wgrad():
+            (q * up).sum().backward()
+        return q.detach().clone(), x.clone(), act.clone(), [t.grad.clone() for t in ps]
+
+    q0, x0, a0, g0 = run(False)
+    q1, x1, a1, g1 = run(True)
+    assert torch.equal(x0, x1)
+    scale = float(q0.abs().max())
+    np.testing.assert_allclose(q1.cpu().numpy(), q0.cpu().numpy(), rtol=0, atol=1e-5 * max(1.0, scale))
+    np.testing.assert_allclose(a1.cpu().numpy(), a0.cpu().numpy(), rtol=0, atol=1e-5 * max(1.0, float(a0.abs().max())))
+    for a, c in zip(g0, g1):
+        np.testing.assert_allclose(c.cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(a.abs().max()))
+    # an activation within rounding of zero may sit on the other side of the ReLU in the two forms; everything else equal
+    flipped = ((a0 > 0) != (a1 > 0)).float().mean().item()
+    assert flipped < 1e-4
+    # the module uses it exactly when the predicate says so
+    monkeypatch.setenv("MACJD_QHEAD_TAKEN", "0")
+    assert not ops.qhead_taken_supported(h, w1, w2, A)
