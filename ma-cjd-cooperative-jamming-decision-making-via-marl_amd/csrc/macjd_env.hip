@@ -227,7 +227,10 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
     // compare / select / fma chains on the VALU, which is the unit this kernel is bound by; row NR takes the
     // contributions of jammers that have none.  Same operations in the same (jammer) order on the same values.
     // (also the per-env-table production variant: its lanes hold ~45 table values each, every register counts)
-    constexpr bool SCAT = REG || (PE && FAST && JT && RT);
+#ifndef MACJD_PE_SCAT
+#define MACJD_PE_SCAT 1   // build knob for A/B runs: 0 keeps the per-env variant's accumulators in registers
+#endif
+    constexpr bool SCAT = REG || (MACJD_PE_SCAT && PE && FAST && JT && RT);
     constexpr int ACC_W = SCAT ? 256 : 1;
     __shared__ double s_supp[SCAT ? NR + 1 : 1][ACC_W], s_prod[SCAT ? NR + 1 : 1][ACC_W];
     __shared__ double s_D[PE ? 1 : NR], s_Pn[PE ? 1 : NR], s_gr[PE ? 1 : NR];
