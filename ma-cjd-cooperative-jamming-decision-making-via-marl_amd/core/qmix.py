@@ -684,12 +684,13 @@ class QMixLearner:
         if not self._g_idx_fresh:
             ops.sample_episodes(self._g_idx, self._g_n_stored, self._g_draws, self._sampler_seed())
 
-    def train_from_buffer_many(self, n):
+    def train_from_buffer_many(self, n, stats_out=None):
         """``n`` consecutive updates on device-drawn batches, the same sequence of updates as ``n`` calls of
         ``train_from_buffer()`` (same draws, same target syncs): groups of K = updates_per_graph updates replay ONE graph
         where nothing has to happen between them (no target sync due inside the group), the rest goes one by one.
         Returns the updates' statistics as float32 [4] device tensors (loss, eval_qtot_avg, target_qtot_avg, grad_norm);
-        the tensors of a replayed group are static outputs that the next replay of the group overwrites."""
+        the tensors of a replayed group are static outputs that the next replay of the group overwrites — pass
+        ``stats_out`` (float32 [n, 4] on the device) to get every update's row snapshotted (one small copy per group)."""
         buf = self._g_buffer if getattr(self, "_graphs_ready", False) else None
         if buf is None:
             raise RuntimeError("call enable_graphs(buffer, batch_size) first")
@@ -705,14 +706,16 @@ class QMixLearner:
                 m[1].replay()
                 self._g_idx_fresh = (buf.store_count, buf.current_size) == self._g_pop_seen
                 self._after_step()
+                if stats_out is not None:
+                    torch.stack(m[2], out=stats_out[done:done + m[0]])
                 out += m[2]
                 done += m[0]
             else:
-                row = torch.empty(4, dtype=torch.float32, device=self.device)
+                row = stats_out[done] if stats_out is not None else torch.empty(4, dtype=torch.float32, device=self.device)
                 self.train_from_buffer(sync_stats=False, stats_row=row)
                 out.append(row)
                 done += 1
-        return out
+        return out if stats_out is None else stats_out
 
     def _sampler_seed(self):
         """Key of the device-side episode sampler: the learner's seed, set apart per rank like the host sampler's."""

@@ -266,7 +266,7 @@ def run(args):
 
         if buffer.current_size >= args.batch_size and total_steps > args.start_training_steps:   # main.py:212
             if use_graphs and not graphs_on:
-                learner.enable_graphs(buffer, args.batch_size)
+                learner.enable_graphs(buffer, args.batch_size, updates_per_graph=int(getattr(args, "updates_per_graph", 10) or 1))
                 runner.enable_graph()
                 graphs_on = True
             num_train_steps = int(getattr(args, "updates_per_rollout", 0) or current_episode_steps // args.train_interval)
@@ -274,7 +274,12 @@ def run(args):
             # every update's four scalars are snapshotted into their own row on the device (the graphed update reuses
             # ONE static output tensor): read back once after the block
             hist = torch.empty((num_train_steps, 4), dtype=torch.float32, device=device) if graphs_on else None
-            for i_upd in range(num_train_steps):
+            if graphs_on and num_train_steps > 0:
+                # groups of `updates_per_graph` updates replay one graph each (their batches are drawn on the device)
+                learner.train_from_buffer_many(num_train_steps, stats_out=hist)
+                pending = [{"loss": hist[i, 0], "grad_norm": hist[i, 3], "eval_qtot_avg": hist[i, 1], "target_qtot_avg": hist[i, 2]}
+                           for i in range(num_train_steps)]
+            for i_upd in range(0 if graphs_on else num_train_steps):
                 if graphs_on:
                     pending.append(learner.train_from_buffer(sync_stats=False, stats_row=hist[i_upd]))
                 else:

@@ -1739,9 +1739,11 @@ def test_updates_grouped_into_one_graph_equal_single_updates():
         assert torch.equal(a, b), k_
     for (k_, a), b in zip(one.target_qmix_net.state_dict().items(), many.target_qmix_net.state_dict().values()):
         assert torch.equal(a, b), k_
-    # one call does the same split on its own
+    # one call does the same split on its own, and snapshots every update's row when asked to
     mac_j, joint = build(K)
-    joint.train_from_buffer_many(n)
+    snap = torch.zeros(n, 4, device=DEV)
+    assert joint.train_from_buffer_many(n, stats_out=snap) is snap
+    np.testing.assert_allclose(snap.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-7)
     assert joint.train_step == n and joint.last_target_update_step == 5
     for (k_, a), b in zip(mac_1.agent.state_dict().items(), mac_j.agent.state_dict().values()):
         assert torch.equal(a, b), k_
