@@ -327,6 +327,12 @@ typedef struct macjd_lnparam_io {
 } macjd_lnparam_io;
 
 int macjd_layernorm_param_grad(const macjd_lnparam_io* io, void* hip_stream);
+/* macjd_clip_adam_step_sample whose FIRST launch also evaluates the LayerNorm parameter gradients (this struct) — they are
+   part of the clipped vector, at elements gamma_off / beta_off of io->grad (ln->dgamma / ln->dbeta must point there), so
+   the squared-norm launch computes them in K extra workgroups and counts their squares itself; the other workgroups skip
+   those two ranges.  One launch less behind the weight-gradient reduce.  io->partials: >= 256 + ln->K floats. */
+int macjd_clip_adam_step_ln(const macjd_adam_io* io, const macjd_sampler_io* next, const macjd_lnparam_io* ln,
+                            int64_t gamma_off, int64_t beta_off, void* hip_stream);
 
 /*
  * Fused chain of up to three dense layers, y = act_n(W_n ... act_1(W_1 x + b_1) ... + b_n), float32 with

@@ -24,7 +24,7 @@ EXPORTS = [
     "macjd_scenario_create", "macjd_scenario_destroy", "macjd_scenario_dims", "macjd_scenario_is_regular",
     "macjd_env_reset", "macjd_env_step", "macjd_env_step_timed",
     "macjd_qhead_select", "macjd_gru_sequence", "macjd_mixer_tail_forward", "macjd_mixer_tail_backward",
-    "macjd_mlp_forward", "macjd_mlp_forward_pair", "macjd_td_loss", "macjd_clip_adam_step", "macjd_clip_adam_step_sample", "macjd_sample_episodes", "macjd_gather_rows",
+    "macjd_mlp_forward", "macjd_mlp_forward_pair", "macjd_td_loss", "macjd_clip_adam_step", "macjd_clip_adam_step_sample", "macjd_clip_adam_step_ln", "macjd_sample_episodes", "macjd_gather_rows",
     "macjd_linear_wgrad", "macjd_linear_wgrad_workspace_floats", "macjd_linear_wgrad_many", "macjd_qhead_input", "macjd_layernorm_forward", "macjd_layernorm_param_grad", "macjd_gru_gates", "macjd_rowdot", "macjd_splitrelu_backward",
     "macjd_mixer_fused_supported", "macjd_mixer_fused_forward", "macjd_mixer_fused_backward",
     "macjd_agent_episode_supported", "macjd_agent_episode", "macjd_env_step_many", "macjd_env_step_many_timed",
@@ -371,6 +371,9 @@ def load() -> ctypes.CDLL:
     lib.macjd_clip_adam_step.argtypes = [ctypes.POINTER(AdamIO), ctypes.c_void_p]
     lib.macjd_clip_adam_step_sample.restype = ctypes.c_int
     lib.macjd_clip_adam_step_sample.argtypes = [ctypes.POINTER(AdamIO), ctypes.POINTER(SamplerIO), ctypes.c_void_p]
+    lib.macjd_clip_adam_step_ln.restype = ctypes.c_int
+    lib.macjd_clip_adam_step_ln.argtypes = [ctypes.POINTER(AdamIO), ctypes.POINTER(SamplerIO), ctypes.POINTER(LnParamIO),
+                                            ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
     lib.macjd_sample_episodes.restype = ctypes.c_int
     lib.macjd_sample_episodes.argtypes = [ctypes.POINTER(SamplerIO), ctypes.c_void_p]
     lib.macjd_gather_rows.restype = ctypes.c_int

@@ -140,7 +140,7 @@ class QMixLearner:
         self._flat_exp_avg_sq = torch.zeros_like(flat)
         self._adam_step = torch.zeros((), dtype=torch.float32, device=flat.device)
         self._grad_norm = torch.zeros((), dtype=torch.float32, device=flat.device)
-        self._adam_partials = torch.zeros(256, dtype=torch.float32, device=flat.device)
+        self._adam_partials = torch.zeros(256 + 1024, dtype=torch.float32, device=flat.device)   # + LayerNorm partials
         for p, off in zip(tr, self._flat_offsets):
             n = p.numel()
             p.data = flat[off:off + n].view_as(p)
@@ -443,8 +443,12 @@ class QMixLearner:
             loss, eval_mean, target_mean, gy, self._last_stats4 = ops.td_loss_and_grad(
                 eval_q_tot, target_q_tot, st["reward"], st["terminated"], st["filled"], self.args.gamma, T - 1, 1)
             # the weight gradients: one grouped launch pair after the chain, written into the flat gradient vector
-            with ops.deferred_wgrad(grad_dst=getattr(self, "_grad_dst", None)):
+            # (single process: the LayerNorm-parameter launch behind the grouped products is held back and evaluated
+            # inside the optimiser step's squared-norm launch — with more ranks the all-reduce needs it done first)
+            hold = self._flat_param is not None and self._world_size() <= 1 and os.environ.get("MACJD_LN_IN_SQNORM", "1") != "0"
+            with ops.deferred_wgrad(grad_dst=getattr(self, "_grad_dst", None), hold_lnparam=hold) as dw:
                 eval_q_tot.backward(gy)
+            self._held_ln = dw.held
         else:
             loss, eval_mean, target_mean = ops.td_loss_full(eval_q_tot, target_q_tot, st["reward"], st["terminated"],
                                                             st["filled"], self.args.gamma, T - 1, 1)
@@ -456,9 +460,10 @@ class QMixLearner:
     def _clip_and_step(self, sample_next=None):
         if self._flat_param is not None:   # HIP device: fused clip_grad_norm_ + Adam on the flat vectors
             g = self.optimizer.param_groups[0]
+            held, self._held_ln = getattr(self, "_held_ln", None), None
             ops.clip_adam_step(self._flat_param, self._flat_grad, self._flat_exp_avg, self._flat_exp_avg_sq,
                                self._adam_step, self._grad_norm, self._adam_partials, g["lr"], g["betas"], g["eps"],
-                               self.args.grad_norm_clip, sample_next=sample_next)
+                               self.args.grad_norm_clip, sample_next=sample_next, lnparam=held)
             return self._grad_norm
         grad_norm = torch.nn.utils.clip_grad_norm_(self.params, self.args.grad_norm_clip)  # qmix.py:199
         self.optimizer.step()

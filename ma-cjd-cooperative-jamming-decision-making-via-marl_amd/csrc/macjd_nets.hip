@@ -844,6 +844,47 @@ __global__ void __launch_bounds__(256) adam_sqnorm_kernel(const macjd_adam_io io
     }
 }
 
+// adam_sqnorm_kernel + lnparam_kernel as one launch (macjd_clip_adam_step_ln): workgroups [0, nb) sum the squares of their
+// slices of the gradient vector EXCEPT the LayerNorm ranges, workgroup nb + k computes dgamma[k] / dbeta[k] with
+// lnparam_kernel's own arithmetic, stores them and contributes their squares as partial nb + k.
+__global__ void __launch_bounds__(256) adam_sqnorm_ln_kernel(const macjd_adam_io io, const macjd_lnparam_io ln, const int64_t g_off,
+                                                             const int64_t b_off, const int nb) {
+    __shared__ float smem[8];
+    if ((int)blockIdx.x < nb) {
+        float s = 0.0f;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < io.n; i += (int64_t)nb * blockDim.x) {
+            const bool is_ln = (i >= g_off && i < g_off + ln.K) || (i >= b_off && i < b_off + ln.K);
+            const float g = is_ln ? 0.0f : io.grad[i];
+            s = fmaf(g, g, s);
+        }
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            io.partials[blockIdx.x] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+            if (blockIdx.x == 0) io.step[0] += 1.0f;   // as in adam_sqnorm_kernel
+        }
+        return;
+    }
+    const int k = (int)blockIdx.x - nb;
+    float sg = 0.0f, sb = 0.0f;
+    for (int c = threadIdx.x; c < ln.C; c += blockDim.x) {
+        const float w = ln.W[(int64_t)c * ln.w_ld + k];
+        sg = fmaf(w, ln.G[(int64_t)c * ln.g_ld + k], sg);
+        sb = fmaf(w, ln.gb[c], sb);
+    }
+    sg = wave_sum(sg);
+    sb = wave_sum(sb);
+    if ((threadIdx.x & 63) == 0) { smem[threadIdx.x >> 6] = sg; smem[4 + (threadIdx.x >> 6)] = sb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float dg = (smem[0] + smem[1]) + (smem[2] + smem[3]), db = (smem[4] + smem[5]) + (smem[6] + smem[7]);
+        ln.dgamma[k] = dg;
+        ln.dbeta[k] = db;
+        io.partials[nb + k] = fmaf(db, db, dg * dg);
+    }
+}
+
 // ---- device-side draw of the next update's episodes (include/macjd_nets.h, macjd_sampler_io) ----
 __device__ __forceinline__ uint32_t fmix32(uint32_t h) {   // MurmurHash3 finaliser
     h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
@@ -969,6 +1010,29 @@ extern "C" int macjd_clip_adam_step_sample(const macjd_adam_io* io, const macjd_
 
 extern "C" int macjd_clip_adam_step(const macjd_adam_io* io, void* hip_stream) {
     return macjd_clip_adam_step_sample(io, nullptr, hip_stream);
+}
+
+extern "C" int macjd_clip_adam_step_ln(const macjd_adam_io* io, const macjd_sampler_io* next, const macjd_lnparam_io* ln,
+                                       int64_t gamma_off, int64_t beta_off, void* hip_stream) {
+    using namespace macjd;
+    if (!io || io->n < 1 || !io->param || !io->grad || !io->exp_avg || !io->exp_avg_sq || !io->step || !io->grad_norm ||
+        !io->partials)
+        return set_nets_err(MACJD_EINVAL, "macjd_clip_adam_step_ln: bad argument");
+    if (next && !sampler_args_ok(next)) return set_nets_err(MACJD_EINVAL, "macjd_clip_adam_step_ln: bad sampler argument");
+    if (!ln || ln->C < 1 || ln->K < 1 || ln->K > 1024 || !ln->W || !ln->G || !ln->gb || ln->w_ld < ln->K || ln->g_ld < ln->K)
+        return set_nets_err(MACJD_EINVAL, "macjd_clip_adam_step_ln: bad LayerNorm argument");
+    if (gamma_off < 0 || beta_off < 0 || gamma_off + ln->K > io->n || beta_off + ln->K > io->n ||
+        ln->dgamma != io->grad + gamma_off || ln->dbeta != io->grad + beta_off)
+        return set_nets_err(MACJD_EINVAL, "macjd_clip_adam_step_ln: dgamma / dbeta must be the named ranges of the gradient vector");
+    hipStream_t s = (hipStream_t)hip_stream;
+    int blocks = (int)((io->n + 255) / 256);
+    if (blocks > ADAM_BLOCKS) blocks = ADAM_BLOCKS;
+    hipLaunchKernelGGL(adam_sqnorm_ln_kernel, dim3(blocks + ln->K), dim3(256), 0, s, *io, *ln, gamma_off, beta_off, blocks);
+    if (next) hipLaunchKernelGGL(adam_update_kernel<true>, dim3(blocks), dim3(256), 0, s, *io, blocks + ln->K, *next);
+    else hipLaunchKernelGGL(adam_update_kernel<false>, dim3(blocks), dim3(256), 0, s, *io, blocks + ln->K, macjd_sampler_io{});
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
+    return MACJD_OK;
 }
 
 extern "C" int macjd_gather_rows(const macjd_gather_io* io, void* hip_stream) {

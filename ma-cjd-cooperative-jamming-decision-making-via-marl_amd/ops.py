@@ -582,6 +582,7 @@ class _FusedMixer(torch.autograd.Function):
             with torch.cuda.device(dev):
                 _native.check(_native.load().macjd_layernorm_param_grad(ctypes.byref(lio), stream), "macjd_layernorm_param_grad")
 
+        post.lnparam = lio   # (a context that holds these launches back hands them to the optimiser step, see deferred_wgrad)
         if _DEFERRED_WGRAD is not None:
             _DEFERRED_POST.append(post)
         else:
@@ -813,19 +814,36 @@ def sample_episodes(idx_out, n_stored, counter, seed):
         _native.check(lib.macjd_sample_episodes(ctypes.byref(sp), _stream(idx_out)), "macjd_sample_episodes")
 
 
-def clip_adam_step(param, grad, exp_avg, exp_avg_sq, step, grad_norm, partials, lr, betas, eps, max_norm, sample_next=None):
+def clip_adam_step(param, grad, exp_avg, exp_avg_sq, step, grad_norm, partials, lr, betas, eps, max_norm, sample_next=None,
+                   lnparam=None):
     """In-place update of ``param`` / ``exp_avg`` / ``exp_avg_sq`` / ``step`` (all flat float32 on one HIP
     device); writes the pre-clip gradient norm into ``grad_norm``.  ``sample_next`` = (idx_out, n_stored, counter,
-    seed): the update launch also draws the NEXT update's episodes (``sample_episodes``) when it is done."""
+    seed): the update launch also draws the NEXT update's episodes (``sample_episodes``) when it is done.
+    ``lnparam`` = LayerNorm-parameter launches held back by ``deferred_wgrad(hold_lnparam=True)``: a single one whose
+    outputs are ranges of ``grad`` is evaluated inside the squared-norm launch; anything else is simply issued first."""
     lib = _native.load()
     io = _native.AdamIO()
     io.n, io.lr, io.beta1, io.beta2, io.eps, io.max_norm = param.numel(), lr, betas[0], betas[1], eps, max_norm
     io.param, io.grad, io.exp_avg, io.exp_avg_sq = param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr()
     io.step, io.grad_norm, io.partials = step.data_ptr(), grad_norm.data_ptr(), partials.data_ptr()
     sp = _sampler_io(*sample_next) if sample_next is not None else None
+    spp = ctypes.byref(sp) if sp is not None else None
+    held = list(lnparam or [])
+    fuse = None
+    if len(held) == 1:
+        lio, esz, base = held[0].lnparam, grad.element_size(), grad.data_ptr()
+        g_off, b_off = (lio.dgamma - base) // esz, (lio.dbeta - base) // esz
+        if ((lio.dgamma - base) % esz == 0 and (lio.dbeta - base) % esz == 0 and 0 <= g_off <= grad.numel() - lio.K
+                and 0 <= b_off <= grad.numel() - lio.K and partials.numel() >= 256 + lio.K):
+            fuse = (lio, int(g_off), int(b_off))
     with torch.cuda.device(param.device):
-        _native.check(lib.macjd_clip_adam_step_sample(ctypes.byref(io), ctypes.byref(sp) if sp is not None else None,
-                                                      _stream(param)), "macjd_clip_adam_step")
+        if fuse is not None:
+            _native.check(lib.macjd_clip_adam_step_ln(ctypes.byref(io), spp, ctypes.byref(fuse[0]), fuse[1], fuse[2],
+                                                      _stream(param)), "macjd_clip_adam_step_ln")
+            return
+        for fn in held:
+            fn()
+        _native.check(lib.macjd_clip_adam_step_sample(ctypes.byref(io), spp, _stream(param)), "macjd_clip_adam_step")
 
 
 def gather_rows_supported(srcs) -> bool:
@@ -878,11 +896,15 @@ class deferred_wgrad:
     the flush: read them only after the context — and let autograd (or the caller) be their only owner until then.
     A parameter used twice in the graph is handled (its second gradient forces the recorded ones out first)."""
 
-    def __init__(self, grad_dst=None):
+    def __init__(self, grad_dst=None, hold_lnparam=False):
         # {grad_key(parameter): preallocated gradient tensor of the parameter's shape}: inside the context the
         # weight / bias gradients of those parameters are written straight into these tensors (slices of the
         # learner's flat gradient vector) and autograd receives fresh views of them — no packing copy afterwards
         self._grad_dst = grad_dst
+        # hold_lnparam: the LayerNorm-parameter launches that follow the grouped products are NOT issued at exit but
+        # collected in ``held`` — the caller passes them to ``clip_adam_step(lnparam=...)``, whose squared-norm launch
+        # evaluates them (one launch less), or calls them itself
+        self._hold, self.held = bool(hold_lnparam), []
 
     def __enter__(self):
         global _DEFERRED_WGRAD, _DEFERRED_POST, _GRAD_DST, _DEFERRED_SEEN
@@ -900,7 +922,10 @@ class deferred_wgrad:
         self._flush(exc, pending)
         if exc[0] is None:
             for fn in post:      # launches that consume the flushed products (e.g. LayerNorm parameter gradients)
-                fn()
+                if self._hold and hasattr(fn, "lnparam"):
+                    self.held.append(fn)
+                else:
+                    fn()
         return False
 
     @staticmethod
@@ -1074,6 +1099,7 @@ class _NormMergedLinear(torch.autograd.Function):
             with torch.cuda.device(dev):
                 _native.check(_native.load().macjd_layernorm_param_grad(ctypes.byref(io), stream), "macjd_layernorm_param_grad")
 
+        post.lnparam = io
         if _DEFERRED_WGRAD is not None:
             _DEFERRED_POST.append(post)      # the products above are only recorded yet: run after the grouped launches
         else:

@@ -1839,3 +1839,54 @@ def test_taken_action_qhead_in_one_launch(n, A, idt, monkeypatch):
     # the module uses it exactly when the predicate says so
     monkeypatch.setenv("MACJD_QHEAD_TAKEN", "0")
     assert not ops.qhead_taken_supported(h, w1, w2, A)
+
+
+def test_layernorm_param_grads_inside_the_squared_norm_launch(monkeypatch):
+    """Single process: the LayerNorm-parameter launch behind the grouped weight gradients is held back and evaluated by
+    the optimiser step's squared-norm launch (macjd_clip_adam_step_ln: K extra workgroups, their squares counted as
+    extra partials, the generic workgroups skip the two ranges) == the separate launch (MACJD_LN_IN_SQNORM=0): same
+    LayerNorm gradients bitwise, the gradient norm to float rounding (the partial sums are grouped differently), same
+    weights after the steps to 1e-6."""
+    from macjd_amd.core.mac import BasicMAC
+    from macjd_amd.core.qmix import QMixLearner
+    from macjd_amd.utils.replay_buffer import EpisodeReplayBuffer
+    from tests_golden_helpers import synthetic_batch
+    g, d = load("3j4r_h64")
+    T, N, B = 100, 40, 32
+    def build():
+        args = _gpu_args(d, episode_limit=T, buffer_size=N, batch_size=B, target_update_interval=50, lr=1e-3)
+        with quiet():
+            mac = BasicMAC(d["S"], args)
+            mac.load_state(sd_from(g, "g5_agent0."))
+            learner = QMixLearner(mac, args)
+            buf = EpisodeReplayBuffer(args)
+        learner.eval_qmix_net.load_state_dict(sd_from(g, "g5_mixer0."))
+        learner._update_targets()
+        full = synthetic_batch(np.random.default_rng(9), args, N, T)
+        for k, v in buf.buffers.items():
+            v.copy_(torch.as_tensor(full[k]).to(v.dtype))
+        buf.current_size, buf.current_index = N, 0
+        buf.episode_lengths[:] = T
+        return mac, learner, buf
+    rng = np.random.default_rng(3)
+    idxs = [rng.choice(N, B, replace=False) for _ in range(3)]
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MACJD_LN_IN_SQNORM", mode)
+        mac, learner, buf = build()
+        stats, ln_grads = [], []
+        for idx in idxs:
+            stats.append(learner.train(buf.sample(B, indices=idx), {}))
+            ln = learner.eval_qmix_net.state_norm
+            ln_grads.append((ln.weight.grad.clone(), ln.bias.grad.clone(), float(stats[-1]["grad_norm"])))
+        out[mode] = (stats, ln_grads, [p.detach().clone() for p in learner.params])
+    for (s1, s0) in zip(out["1"][0], out["0"][0]):
+        for k in s1:
+            assert s1[k] == pytest.approx(s0[k], rel=1e-6, abs=1e-9), k
+    # .grad holds the CLIPPED gradients after the step: compare through the clip coefficient of each run
+    for (w1, b1, n1), (w0, b0, n0) in zip(out["1"][1], out["0"][1]):
+        np.testing.assert_allclose(w1.cpu().numpy(), w0.cpu().numpy(), rtol=2e-6, atol=1e-12)
+        np.testing.assert_allclose(b1.cpu().numpy(), b0.cpu().numpy(), rtol=2e-6, atol=1e-12)
+        assert float(w1.abs().max()) > 0
+    for a, c in zip(out["1"][2], out["0"][2]):
+        np.testing.assert_allclose(a.cpu().numpy(), c.cpu().numpy(), rtol=0, atol=1e-6)
