@@ -53,6 +53,9 @@ def _make_step_fn(cli, runner, learner, buf, args, T, mode, use_graphs, tails):
             left = region - j
             if fused:   # the whole (or the region's partial) episode batch: agent-episode launch + many-step env launch
                 state["graphed_episode"] = True
+                # (measured and dropped: the batch's launches on their own stream beside the updates of its first steps —
+                # identical results with a Q-head snapshot, but the 0.75 ms agent kernel on every CU slows the updates
+                # it overlaps by more than it hides: 0.1688 vs 0.1670 ms / step)
                 runner.rollout_fused(n_steps=None if left >= T else left)
             else:
                 state["graphed_episode"] = use_graphs and (left >= T or left in tails)
@@ -90,7 +93,6 @@ def make_step(cli, sc, env, dev, rank, world, mode):
     args = make_args(sc, cli.hidden, dev, batch_envs=env.batch_envs)
     gemm_tuning = False
     if not getattr(cli, "no_gemm_tuning", False):
-        import os
         import tempfile
         from . import ops
         gemm_tuning = ops.enable_gemm_tuning(os.path.join(tempfile.gettempdir(), f"macjd_tunableop_rank{rank}.csv"))
@@ -124,6 +126,7 @@ def make_step(cli, sc, env, dev, rank, world, mode):
         for n in sorted(tails):
             runner.enable_graph(n_steps=n)
     step_fn = _make_step_fn(cli, runner, learner if mode == "train" else None, buf, args, T, mode, use_graphs, tails)
+    step_fn.runner, step_fn.learner, step_fn.buffer = runner, learner, buf   # (for tests and probes)
 
     extra = {"hidden": cli.hidden, "train_batch_episodes": args.batch_size if mode == "train" else 0,
              "train_calls_per_step": 1 if mode == "train" else 0,
