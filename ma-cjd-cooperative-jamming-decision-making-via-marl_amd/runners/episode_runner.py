@@ -312,7 +312,7 @@ class BatchedEpisodeRunner:
         eps = np.zeros(T, dtype=np.float32)
         for t in range(n):
             eps[t] = sel.anneal(self.t_env + t, test_mode=False)
-        self._eps_sched.copy_(torch.from_numpy(eps))
+        self._upload_eps_schedule(eps)
         self._ep += 1
         self._ctr_base.fill_(self._ep * (T + 1))
         self._graphs[n].replay()
@@ -332,6 +332,22 @@ class BatchedEpisodeRunner:
         from .. import ops
         return (getattr(self.env, "kernel_flags", 0) == 0
                 and ops.agent_episode_supported(self.n_agents, agent.rnn_hidden_dim, agent.n_actions))
+
+    def _upload_eps_schedule(self, eps: np.ndarray):
+        """The episode batch's exploration schedule -> device, through one of two pinned buffers (a copy from pageable memory
+        makes the host wait for the stream: the launches of the batch would then start only after everything issued before
+        has drained)."""
+        ring = getattr(self, "_eps_ring", None)
+        if ring is None:
+            ring = self._eps_ring = [(torch.zeros(self.episode_limit, dtype=torch.float32).pin_memory(), torch.cuda.Event())
+                                     for _ in range(2)]
+            self._eps_slot = 0
+        self._eps_slot ^= 1
+        buf, ev = ring[self._eps_slot]
+        ev.synchronize()                       # the copy that last read this buffer is done (two batches ago)
+        buf.numpy()[:len(eps)] = eps
+        self._eps_sched.copy_(buf, non_blocking=True)
+        ev.record()
 
     def rollout_fused(self, test_mode=False, n_steps=None):
         """One episode batch (or its first ``n_steps`` steps) in THREE launches: ``ops.agent_episode`` (GRU cell + all-action
@@ -356,7 +372,7 @@ class BatchedEpisodeRunner:
         eps = np.zeros(T, dtype=np.float32)
         for t in range(n):
             eps[t] = sel.anneal(self.t_env + t, test_mode=test_mode)
-        self._eps_sched.copy_(torch.from_numpy(eps))
+        self._upload_eps_schedule(eps)
         self.begin_episodes()                       # episode index, zero hidden state, env reset, static rows + inputs
         self._ctr_base.fill_(self._ep * (T + 1))
         params, gi = mac.static_inputs
