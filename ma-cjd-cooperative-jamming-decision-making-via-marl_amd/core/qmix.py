@@ -303,13 +303,18 @@ class QMixLearner:
             return ([h[0], h[0]] if shared else h), None
         return ([h[0], h[0]] if shared else h), ([ps[0], ps[0]] if shared else ps)
 
-    def _forward_backward_full(self, st, T, pre_scan=None, pre_actor=None):
+    def _forward_backward_full(self, st, T, pre_scan=None, pre_actor=None, prefetched=None, after_join=None):
         """Same update as ``_forward_backward`` for a batch of FULL-LENGTH episodes held in contiguous staging
         tensors with T+1 steps on every key (actions padded with a zero row).  Every quantity is evaluated for
         all T+1 steps and the loss kernel picks the steps it needs through strides, so no slice of a [B,T+1,...]
         tensor is ever reshaped (= copied) and autograd sees no slicing (no zero-fill + copy in backward).
         Rows that the reference never evaluates (eval step T-1 and T, target step 0) cost ~2 % extra arithmetic,
-        receive zero gradient and do not enter the loss: the result equals ``_forward_backward`` (tested)."""
+        receive zero gradient and do not enter the loss: the result equals ``_forward_backward`` (tested).
+
+        ``prefetched`` = (gather_done, scan_done) events: ``st`` was gathered and ``pre_scan`` / ``pre_actor`` were
+        computed on the side stream during the PREVIOUS update (enable_graphs, pipelined group) — no fork here, the
+        origin stream waits for the two events where it needs the data.  ``after_join()`` is called right behind the join:
+        the place from which the next update's batch is prefetched."""
         B, T1 = st["state"].shape[0], T + 1
         J, H, A = self.n_agents, self.args.rnn_hidden_dim, self.n_actions
         n = B * T1 * J
@@ -398,10 +403,15 @@ class QMixLearner:
             if getattr(self, "_target_stream", None) is None:
                 self._target_stream = torch.cuda.Stream(device=dev)
             ts = self._target_stream
-            ts.wait_stream(origin)                                                              # fork
-            with torch.cuda.stream(ts), torch.no_grad():
-                bases = scan_chain()
-                p_target = None if (shared or pre_actor is not None) else actor_all(macs[0].agent)
+            if prefetched is None:
+                ts.wait_stream(origin)                                                          # fork
+                with torch.cuda.stream(ts), torch.no_grad():
+                    bases = scan_chain()
+                    p_target = None if (shared or pre_actor is not None) else actor_all(macs[0].agent)
+            else:
+                assert pre_scan is not None and pre_actor is not None
+                origin.wait_event(prefetched[0])                                                # the gathered batch is there
+                bases, p_target = scan_chain(), None                                            # (views of pre_scan: no launch)
             if pre_actor is not None:      # [B, J, A] per controller, from the scan launch's prologue: [target, eval]
                 p_target, p_eval = (None if shared else pre_actor[0]), pre_actor[1]
             eval_q_tot = eval_forward()
@@ -412,7 +422,12 @@ class QMixLearner:
                 # unfused mixer: its state-only half (LayerNorm + hyper-networks) runs here, before the join; the fused
                 # mixer is ONE launch that needs the target Q-values, i.e. it runs behind the join
                 hyper = None if self.target_qmix_net.fused_available(st["state"]) else self.target_qmix_net.hyper_outputs(st["state"])
-                origin.wait_stream(ts)                                                          # join
+                if prefetched is None:
+                    origin.wait_stream(ts)                                                      # join
+                else:
+                    origin.wait_event(prefetched[1])                                            # join (the scan ended long ago)
+                if after_join is not None:
+                    after_join()
                 for t_ in list(bases) + ([p_target] if p_target is not None else []) + ([p_eval] if pre_actor is not None else []):
                     t_.record_stream(origin)
                 if pre_actor is not None and not fused_dq:
@@ -612,14 +627,62 @@ class QMixLearner:
         self._g_multi = None
         if K > 1 and self._g_single and self._g_dev_sampler and fused and self._g_stats4 is not None:
             gm, rows, single_norm = torch.cuda.CUDAGraph(), [], self._grad_norm
+            # Inside the group the updates are software-pipelined: everything of update k + 1 that depends on neither the
+            # weights nor update k's results — the draw of its episodes, the gather into the OTHER staging set, the scan
+            # launch (frozen body) — is issued on the side stream right behind update k's join and runs beside update k's
+            # serial tail; update k + 1 then starts at its taken-action Q-head and finds the scan done at its join
+            # (-17 us per pipelined update: the gather, its hand-over and the wait for the scan leave the chain).  Same
+            # launches on the same data in an order that respects every dependence: same results (tested bitwise).
+            pipelined = (self._g_scan_from_ring and self._g_actor_in_scan and os.environ.get("MACJD_UPDATE_STREAMS", "2") != "1"
+                         and os.environ.get("MACJD_PIPELINED_GROUP", "1") != "0")
+            stage2 = {k: torch.zeros_like(v) for k, v in stage.items()} if pipelined else None
+            stages = [stage, stage2]
+            origin_dev = self.device
+
+            def prefetch(dst):
+                """draw + gather + scan of the NEXT update on the side stream (called behind the current join)"""
+                origin = torch.cuda.current_stream(origin_dev)
+                ts = self._target_stream
+                ts.wait_stream(origin)      # (fork off the origin stream) the previous users of idx / dst are done
+                shared = self._body_is_shared()
+                agents = [self.mac.agent] if shared else [self.target_mac.agent, self.mac.agent]
+                with torch.cuda.stream(ts), torch.no_grad():
+                    ops.sample_episodes(self._g_idx, self._g_n_stored, self._g_draws, self._sampler_seed())
+                    ops.gather_rows(self._g_idx, srcs, [dst[k] for k in keys])
+                    ev_g = torch.cuda.Event()
+                    ev_g.record(ts)
+                    h, ps = ops.gru_sequence_from_obs(buffer.buffers["obs"], self._g_idx, agents, self._g_B, self.n_agents,
+                                                      self._g_T + 1, with_actor=True)
+                    ev_s = torch.cuda.Event()
+                    ev_s.record(ts)
+                return (([h[0], h[0]] if shared else h), ([ps[0], ps[0]] if shared else ps), (ev_g, ev_s))
+
             with torch.cuda.graph(gm, pool=self._graph_a.pool(), capture_error_mode="thread_local"):
-                for _ in range(K):
-                    body_a()
+                nxt_batch = None
+                for k_upd in range(K):
+                    last = k_upd == K - 1
+                    box = {}
+                    hook = (lambda: box.__setitem__("next", prefetch(stages[(k_upd + 1) % 2]))) if (pipelined and not last) else None
+                    if pipelined and nxt_batch is not None:
+                        h_pre, p_pre, evs = nxt_batch
+                        self._forward_backward_full(stages[k_upd % 2], self._g_T, pre_scan=h_pre, pre_actor=p_pre,
+                                                    prefetched=evs, after_join=hook)
+                    elif pipelined:
+                        pre = self._scan_from_ring_early()
+                        ops.gather_rows(self._g_idx, srcs, [stage[k] for k in keys])
+                        self._forward_backward_full(stage, self._g_T, pre_scan=pre[0], pre_actor=pre[1], after_join=hook)
+                    else:
+                        body_a()
+                    nxt_batch = box.get("next")
                     rows.append(self._last_stats4)          # this update's (loss, mean Q_tot, mean target, grad norm)
                     self._grad_norm = rows[-1][3]
-                    self._clip_and_step(sample_next=nxt)
+                    # the update's last launch draws the next batch — unless the prefetch behind the join has done so
+                    self._clip_and_step(sample_next=None if nxt_batch is not None else nxt)
+                if pipelined:
+                    torch.cuda.current_stream(self.device).wait_stream(self._target_stream)   # every fork rejoins
             self._grad_norm = single_norm
             self._g_multi = (K, gm, rows)
+            self._g_pipelined = pipelined
         self._g_shared_body = self._body_is_shared()   # baked into the captured launches
         assert self._g_obs_static == (bool(getattr(buffer, "obs_static", False)) and os.environ.get("MACJD_LEARNER_STATIC_OBS", "1") != "0")
         self._graphs_ready = True
