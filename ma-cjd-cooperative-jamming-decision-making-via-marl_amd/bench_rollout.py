@@ -115,7 +115,7 @@ def make_step(cli, sc, env, dev, rank, world, mode):
     if mode == "train":
         runner.run(test_mode=False, sync_stats=False)  # untimed pre-fill of the replay buffer
         if use_graphs:
-            learner.enable_graphs(buf, args.batch_size, updates_per_graph=int(os.environ.get("MACJD_UPDATES_PER_GRAPH", "10")))
+            learner.enable_graphs(buf, args.batch_size, updates_per_graph=int(os.environ.get("MACJD_UPDATES_PER_GRAPH", "20")))
     tails = set()
     fused_rollout = use_graphs and runner.fused_rollout_available()
     if use_graphs and not fused_rollout:

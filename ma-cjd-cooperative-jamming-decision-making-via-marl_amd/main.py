@@ -266,7 +266,7 @@ def run(args):
 
         if buffer.current_size >= args.batch_size and total_steps > args.start_training_steps:   # main.py:212
             if use_graphs and not graphs_on:
-                learner.enable_graphs(buffer, args.batch_size, updates_per_graph=int(getattr(args, "updates_per_graph", 10) or 1))
+                learner.enable_graphs(buffer, args.batch_size, updates_per_graph=int(getattr(args, "updates_per_graph", 20) or 1))
                 runner.enable_graph()
                 graphs_on = True
             num_train_steps = int(getattr(args, "updates_per_rollout", 0) or current_episode_steps // args.train_interval)
