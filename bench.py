@@ -238,6 +238,22 @@ def main():
                     env_.reset()
                 env_.step(T, P)
             return fn, {}
+        if which == "env_many_step":
+            # the env kernel as the rollout launches it: all steps of an episode batch in ONE launch (macjd_env_step_many),
+            # synthetic actions of every step resident in HBM; episodes aligned to the timed regions like the rollout's
+            Tn = sc.episode_limit
+            Tm_ = torch.randint(0, 2 * R + 1, (Tn, E, J), generator=g, device=dev, dtype=torch.int32)
+            Pm_ = torch.rand((Tn, E, J), generator=g, device=dev)
+            rew_, ter_ = torch.zeros((Tn, E), device=dev), torch.zeros((Tn, E), dtype=torch.uint8, device=dev)
+            rd_ = torch.zeros((Tn, E, 3), device=dev)
+
+            def fn(i):
+                j, region = (i, cli.warmup) if i < cli.warmup else (i - cli.warmup, cli.steps)
+                if j % Tn == 0:
+                    n_ = min(Tn, region - j)
+                    env_.reset()
+                    env_.step_many(Tm_[:n_], Pm_[:n_], rew_[:n_], ter_[:n_], rd_[:n_])
+            return fn, {}
         return bench_mod.make_step(cli, sc, env_, dev, rank, world, which)   # aligns its episodes to cli.warmup / cli.steps
 
     def timed(fn, warmup, steps):
@@ -261,15 +277,15 @@ def main():
     # ---- the other two modes of SURVEY.md 8(d) in the same run (single process; shorter regions) ----
     modes = {mode: round(dt / args.steps * 1e3, 4)}
     if world == 1 and bench_mod is not None and not args.no_other_modes:
-        for which in ("env", "rollout", "train"):
-            if which in modes:
+        for which in ("env", "env_many_step", "rollout", "train"):
+            if which in modes or (which == "env_many_step" and (args.per_env or E * sc.episode_limit > (1 << 24))):
                 continue
             e2 = make_env()
             e2.reset()
             cli2 = argparse.Namespace(**vars(args))
-            cli2.steps, cli2.warmup = (300, 100) if which != "env" else (1000, 100)
+            cli2.steps, cli2.warmup = (300, 100) if which in ("rollout", "train") else (1000, 100)
             fn2, _ = build_step(which, e2, cli2)
-            modes[which] = round(timed(fn2, cli2.warmup, cli2.steps) / cli2.steps * 1e3, 4)
+            modes[which] = round(timed(fn2, cli2.warmup, cli2.steps) / cli2.steps * 1e3, 5 if which == "env_many_step" else 4)
             del fn2
             torch.cuda.synchronize()
 
@@ -434,7 +450,9 @@ def main():
                                    + (", per-env randomised scenarios" if args.per_env else ""),
                        "mode": mode, "per_gpu_env_steps_per_s": round(E * args.steps / dt, 1), **extra},
             "roofline": roofline,
-            # ms per batched step of each mode of SURVEY.md 8(d): (i) env kernel only, (ii) rollout, (iii) rollout + training
+            # ms per batched step of each mode of SURVEY.md 8(d): (i) env kernel only — `env`: one launch per step through
+            # the single-step API (host-enqueue bound), `env_many_step`: the launch the rollout issues, all steps of an
+            # episode batch at once — (ii) rollout, (iii) rollout + training
             "modes_ms_per_step": modes,
         }
         if "train" in modes:

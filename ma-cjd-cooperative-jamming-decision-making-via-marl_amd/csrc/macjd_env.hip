@@ -848,17 +848,25 @@ __global__ void env_reset_kernel(int64_t n_envs, int R, uint8_t* track, int64_t 
 }
 
 // second half of macjd_env_step_many: the step counters advance by T, the per-episode reward-component sums get the T
-// steps' (r_d, r_p, r_j) added in step order (deterministic)
+// steps' (r_d, r_p, r_j) added in step order (deterministic).  One thread per (env, component): for a given step the
+// 3 E values are contiguous, so every load of a wave is one coalesced row piece (one thread per env walking its three
+// columns through [T, E, 3] was 31 us at E = 4096, T = 100), eight steps' loads in flight.
 __global__ void env_advance_kernel(int64_t n_envs, int32_t T, int32_t* step, const float* r_dpj, float* r_dpj_sum) {
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_envs; e += (int64_t)gridDim.x * blockDim.x) {
-        step[e] += T;
+    const int64_t n3 = n_envs * 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < n_envs) step[i] += T;
         if (r_dpj && r_dpj_sum) {
-            float a = r_dpj_sum[e * 3 + 0], b = r_dpj_sum[e * 3 + 1], c = r_dpj_sum[e * 3 + 2];
-            for (int t = 0; t < T; ++t) {
-                const float* p = r_dpj + ((int64_t)t * n_envs + e) * 3;
-                a += p[0]; b += p[1]; c += p[2];
+            float a = r_dpj_sum[i];
+            int t = 0;
+            for (; t + 8 <= T; t += 8) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = r_dpj[(int64_t)(t + k) * n3 + i];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a += v[k];
             }
-            r_dpj_sum[e * 3 + 0] = a; r_dpj_sum[e * 3 + 1] = b; r_dpj_sum[e * 3 + 2] = c;
+            for (; t < T; ++t) a += r_dpj[(int64_t)t * n3 + i];
+            r_dpj_sum[i] = a;
         }
     }
 }
@@ -1126,7 +1134,7 @@ int macjd_env_step_many(const macjd_scenario* s, const macjd_step_io* io, int32_
     if (io->n_envs == 0) return MACJD_OK;
     rc = launch_step(s, io, (hipStream_t)hip_stream, n_steps, t_stride);
     if (rc != MACJD_OK) return rc;
-    int64_t grid = (io->n_envs + 255) / 256;
+    int64_t grid = (io->n_envs * 3 + 255) / 256;
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(macjd::env_advance_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)hip_stream, io->n_envs,
                        n_steps, io->step, io->r_dpj, io->r_dpj_sum);
