@@ -57,11 +57,19 @@ class BasicMAC:
         same vector (shared scenario: the observation is a stride-0 broadcast) — instead of at each of the
         episode_limit steps.  ``obs_batch`` [E, J, S]; pass None to go back to per-step evaluation."""
         if obs_batch is None:
-            self.static_inputs = None
+            self.static_inputs, self._static_key = None, None
             return
         device = next(self.agent.parameters()).device
         obs = obs_batch.to(device) if obs_batch.device != device else obs_batch
         E, J, S = obs.shape
+        # the same observation tensor and an unchanged agent body (everything but the Q-head: frozen in reference-faithful
+        # training) give the same tensors as last time: nothing to launch (version counters see every in-place write)
+        key = (obs.data_ptr(), obs._version, tuple(obs.shape), tuple(obs.stride()),
+               tuple((p.data_ptr(), p._version) for n_, p in self.agent.named_parameters() if not n_.startswith("fc2_q_head")))
+        capturing = obs.is_cuda and torch.cuda.is_current_stream_capturing()   # a captured rollout recomputes at every replay
+        if self.static_inputs is not None and getattr(self, "_static_key", None) == key and not capturing:
+            return
+        self._static_key = None if capturing else key
         with torch.no_grad():
             if obs.stride(0) == 0 and obs.stride(1) == 0:            # one vector broadcast over envs and agents
                 p1, g1 = self.agent.static_step_inputs(obs[0, 0].reshape(1, S))
