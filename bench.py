@@ -332,6 +332,8 @@ def main():
                 "timing": "HIP events around 50 launches replayed from one HIP graph on their own stream (macjd_env_step_many_timed); "
                           "the rocprofv3 kernel-trace summary of the rollout (profiles/r02*_bench_rollout_kernel_stats.csv) has the same kernel",
                 "traffic_measured_in_run": False,
+                "limiter": "VALU issue, not HBM: ~1043 VALU instructions per env-step (float64 SNR / detection-probability "
+                           "arithmetic incl. 7 exp, 2 Philox blocks) for 41 bytes; traffic = 1.01x algorithmic (DESIGN.md 4.1)",
                 "bytes_per_env_step": round(B_many, 2), "env_steps_per_launch": Tn * E,
                 "single_step_launch": single}
     prof_m = profiled_kernel_time("env_step_kernel<", args.per_env, pattern="r*_bench_rollout_kernel_stats.csv")
