@@ -145,3 +145,54 @@ def test_bench_step_accounting_is_region_aligned():
         assert pre == warmup
         assert not any(kind == "step" for ev in per_step for kind, _ in ev)   # every step comes from a graph
         assert sum(1 for ev in timed for kind, _ in ev if kind == "end") == steps // T
+
+
+def test_bench_train_schedule_issues_one_update_per_step_in_groups():
+    """bench_rollout's train schedule with grouped updates: the updates of steps j-K+1 .. j are issued together after step j
+    (one replayed graph), a region's remainder is flushed at its last step — every region does exactly one update per step,
+    none is carried from the warm-up into the timed region — and the fused rollout launches whole (or region-cut) episodes."""
+    from types import SimpleNamespace
+    import macjd_amd.bench_rollout as br
+
+    T, K = 100, 20
+
+    class FakeRunner:
+        def __init__(self):
+            self.log = []
+
+        def fused_rollout_available(self):
+            return True
+
+        def rollout_fused(self, n_steps=None):
+            self.log.append(("rollout", T if n_steps is None else n_steps))
+
+        def end_episodes(self):
+            self.log.append(("end", 0))
+
+    class FakeLearner:
+        _g_multi = (K, None, None)
+
+        def __init__(self, log):
+            self.log = log
+
+        def train_from_buffer_many(self, n):
+            self.log.append(("updates", n))
+
+    for warmup, steps in ((5, 20), (100, 1000), (30, 250), (0, 100), (7, 45)):
+        runner = FakeRunner()
+        learner = FakeLearner(runner.log)
+        cli = SimpleNamespace(warmup=warmup, steps=steps)
+        step_fn = br._make_step_fn(cli, runner, learner, None, SimpleNamespace(batch_size=32), T, "train", True, set())
+        marks = []
+        for i in range(warmup + steps):
+            n0 = len(runner.log)
+            step_fn(i)
+            marks.append(runner.log[n0:])
+        for lo, hi, n in ((0, warmup, warmup), (warmup, warmup + steps, steps)):
+            evs = [e for m in marks[lo:hi] for e in m]
+            assert sum(c for k, c in evs if k == "updates") == n, (warmup, steps)
+            assert sum(c for k, c in evs if k == "rollout") == n, (warmup, steps)
+            assert all(c <= K for k, c in evs if k == "updates")
+        # inside the timed region full groups are the rule: at most one short group per episode boundary / region end
+        timed = [c for m in marks[warmup:] for k, c in m if k == "updates"]
+        assert sum(1 for c in timed if c < K) <= 1
