@@ -320,8 +320,9 @@ def main():
     # algorithmic (compulsory) bytes per env-step of THIS launch: T 4J + P 4J read, reward 4 + (r_d,r_p,r_j) 12 +
     # terminated 1 written by every work item; the env's step counter 4 + episode index 4 are read by each of its T work
     # items but are ONE HBM read per env (the other T - 1 hit L2: PMC traffic = 1.01x this count), and track R is written
-    # once per env: (8 + R) / T per env-step; per-env tables are read by every step's work item
-    B_many = 8 * J + 4 + 12 + 1 + (8 + R) / Tn + (per_env_table_bytes(J, R) if args.per_env else 0)
+    # once per env: (8 + R) / T per env-step; per-env tables likewise — an env's table column is read by each of its T work
+    # items but comes from HBM once
+    B_many = 8 * J + 4 + 12 + 1 + (8 + R + (per_env_table_bytes(J, R) if args.per_env else 0)) / Tn
     ach_m = Tn * E * B_many / (ms_m * 1e-3) / 1e9
     roofline = {"bound": "hbm", "achieved": round(ach_m, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach_m / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(J, R, E, args.per_env, many=True)[0],
