@@ -398,7 +398,32 @@ class QMixLearner:
             return self.eval_qmix_net(q_taken, st["state"])                                    # [B,T+1,1], qmix.py:187
 
         two_streams = dev.type == "cuda" and os.environ.get("MACJD_UPDATE_STREAMS", "2") != "1"
-        if two_streams:
+        # A prefetched update (pipelined group) has the scan's outputs at its very start, so its whole TARGET branch —
+        # Double-DQN launch and target mixer, which read the scan, the Q-heads and the target mixer but nothing of the eval
+        # head — runs on the side stream BESIDE the eval head (taken-action Q-head + eval mixer on this stream) instead
+        # of behind it; the two meet at the TD loss.  (-22 us of a 147 us update.)
+        target_beside_head = (two_streams and prefetched is not None and fused_dq and pre_actor is not None
+                              and self.target_qmix_net.fused_available(st["state"])
+                              and os.environ.get("MACJD_TARGET_BESIDE_HEAD", "1") != "0")
+        if target_beside_head:
+            origin = torch.cuda.current_stream(dev)
+            ts = self._target_stream
+            ts.wait_stream(origin)           # (fork) the previous update's Adam has written the Q-head this branch reads
+            with torch.cuda.stream(ts), torch.no_grad():
+                # scan outputs, actor rows and the gathered batch were produced on this very stream: stream order
+                bases = scan_chain()
+                p_eval = pre_actor[1]
+                params = [p_eval if shared else pre_actor[0], p_eval]
+                target_q_tot = self.target_qmix_net(double_q(bases, params), st["state"])       # qmix.py:138-151
+                target_done = torch.cuda.Event()
+                target_done.record(ts)
+            origin.wait_event(prefetched[0])                                                    # the gathered batch is there
+            eval_q_tot = eval_forward()
+            origin.wait_event(target_done)                                                      # join
+            if after_join is not None:
+                after_join()
+            target_q_tot.record_stream(origin)
+        elif two_streams:
             origin = torch.cuda.current_stream(dev)
             if getattr(self, "_target_stream", None) is None:
                 self._target_stream = torch.cuda.Stream(device=dev)
