@@ -417,11 +417,15 @@ class QMixLearner:
                 target_q_tot = self.target_qmix_net(double_q(bases, params), st["state"])       # qmix.py:138-151
                 target_done = torch.cuda.Event()
                 target_done.record(ts)
+            if after_join is not None:
+                # the NEXT update's prefetch goes straight behind the target branch on the side stream: the index tensor
+                # and the other staging set are free already (their last readers ran earlier on that stream / before the
+                # previous Adam), so it needs no wait for this stream and overlaps the eval head and the loss rather than
+                # the weight-gradient launch (0.1461 -> 0.1440 ms)
+                after_join(False)
             origin.wait_event(prefetched[0])                                                    # the gathered batch is there
             eval_q_tot = eval_forward()
             origin.wait_event(target_done)                                                      # join
-            if after_join is not None:
-                after_join()
             target_q_tot.record_stream(origin)
         elif two_streams:
             origin = torch.cuda.current_stream(dev)
@@ -664,11 +668,12 @@ class QMixLearner:
             stages = [stage, stage2]
             origin_dev = self.device
 
-            def prefetch(dst):
+            def prefetch(dst, fork=True):
                 """draw + gather + scan of the NEXT update on the side stream (called behind the current join)"""
                 origin = torch.cuda.current_stream(origin_dev)
                 ts = self._target_stream
-                ts.wait_stream(origin)      # (fork off the origin stream) the previous users of idx / dst are done
+                if fork:
+                    ts.wait_stream(origin)  # (fork off the origin stream) the previous users of idx / dst are done
                 shared = self._body_is_shared()
                 agents = [self.mac.agent] if shared else [self.target_mac.agent, self.mac.agent]
                 with torch.cuda.stream(ts), torch.no_grad():
@@ -687,7 +692,7 @@ class QMixLearner:
                 for k_upd in range(K):
                     last = k_upd == K - 1
                     box = {}
-                    hook = (lambda: box.__setitem__("next", prefetch(stages[(k_upd + 1) % 2]))) if (pipelined and not last) else None
+                    hook = (lambda fork=True: box.__setitem__("next", prefetch(stages[(k_upd + 1) % 2], fork))) if (pipelined and not last) else None
                     if pipelined and nxt_batch is not None:
                         h_pre, p_pre, evs = nxt_batch
                         self._forward_backward_full(stages[k_upd % 2], self._g_T, pre_scan=h_pre, pre_actor=p_pre,
