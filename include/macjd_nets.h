@@ -158,6 +158,9 @@ typedef struct macjd_tdloss_io {
 } macjd_tdloss_io;
 
 int macjd_td_loss(const macjd_tdloss_io* io, void* hip_stream);
+/* out[0] = sum of the loss mask (io->filled over B x Tm1; the other fields are not read): the only global quantity the
+   gradient of the loss needs — see macjd_mixer_fused_backward_td. */
+int macjd_td_mask_sum(const macjd_tdloss_io* io, float* out, void* hip_stream);
 
 /*
  * Gradient clipping + Adam over ONE flat parameter vector (reference core/qmix.py:199-200:
@@ -476,6 +479,11 @@ typedef struct macjd_mixerf_io {
 int macjd_mixer_fused_supported(int32_t J, int32_t S, int32_t Hh, int32_t Em);   /* 1 / 0 */
 int macjd_mixer_fused_forward(const macjd_mixerf_io* io, void* hip_stream);
 int macjd_mixer_fused_backward(const macjd_mixerf_io* io, void* hip_stream);
+/* macjd_mixer_fused_backward that forms dL/dy itself from the TD loss's inputs (macjd_td_loss's expression; td->y = this
+   mixer's forward output, td->tq the target values, rows = td->B x td->gy_cols) and tot_m[0] = the batch's mask sum
+   (macjd_td_mask_sum): io->gy is not read, td->stats / td->gy are not written.  Takes the loss launch off the update's
+   serial chain; bit-identical gradients. */
+int macjd_mixer_fused_backward_td(const macjd_mixerf_io* io, const macjd_tdloss_io* td, const float* tot_m, void* hip_stream);
 
 /*
  * The agent side of a WHOLE episode batch in one launch: for t = 0 .. T-1 and every (env, agent) row

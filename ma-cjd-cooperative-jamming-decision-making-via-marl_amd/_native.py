@@ -26,7 +26,7 @@ EXPORTS = [
     "macjd_qhead_select", "macjd_gru_sequence", "macjd_mixer_tail_forward", "macjd_mixer_tail_backward",
     "macjd_mlp_forward", "macjd_mlp_forward_pair", "macjd_td_loss", "macjd_clip_adam_step", "macjd_clip_adam_step_sample", "macjd_clip_adam_step_ln", "macjd_sample_episodes", "macjd_gather_rows",
     "macjd_linear_wgrad", "macjd_linear_wgrad_workspace_floats", "macjd_linear_wgrad_many", "macjd_qhead_input", "macjd_layernorm_forward", "macjd_layernorm_param_grad", "macjd_gru_gates", "macjd_rowdot", "macjd_splitrelu_backward",
-    "macjd_mixer_fused_supported", "macjd_mixer_fused_forward", "macjd_mixer_fused_backward",
+    "macjd_mixer_fused_supported", "macjd_mixer_fused_forward", "macjd_mixer_fused_backward", "macjd_mixer_fused_backward_td", "macjd_td_mask_sum",
     "macjd_agent_episode_supported", "macjd_agent_episode", "macjd_env_step_many", "macjd_env_step_many_timed",
     "macjd_qhead_double_q_supported", "macjd_qhead_double_q", "macjd_qhead_taken_supported", "macjd_qhead_taken",
 ]
@@ -345,6 +345,10 @@ def load() -> ctypes.CDLL:
     for name in ("macjd_mixer_fused_forward", "macjd_mixer_fused_backward"):
         getattr(lib, name).restype = ctypes.c_int
         getattr(lib, name).argtypes = [ctypes.POINTER(MixerFusedIO), ctypes.c_void_p]
+    lib.macjd_mixer_fused_backward_td.restype = ctypes.c_int
+    lib.macjd_mixer_fused_backward_td.argtypes = [ctypes.POINTER(MixerFusedIO), ctypes.POINTER(TdLossIO), ctypes.c_void_p, ctypes.c_void_p]
+    lib.macjd_td_mask_sum.restype = ctypes.c_int
+    lib.macjd_td_mask_sum.argtypes = [ctypes.POINTER(TdLossIO), ctypes.c_void_p, ctypes.c_void_p]
     lib.macjd_qhead_taken_supported.restype = ctypes.c_int
     lib.macjd_qhead_taken_supported.argtypes = [ctypes.c_int32, ctypes.c_int32]
     lib.macjd_qhead_taken.restype = ctypes.c_int

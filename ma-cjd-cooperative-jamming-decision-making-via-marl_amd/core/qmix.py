@@ -427,6 +427,7 @@ class QMixLearner:
             eval_q_tot = eval_forward()
             origin.wait_event(target_done)                                                      # join
             target_q_tot.record_stream(origin)
+            return self._finish_update(st, T, eval_q_tot, target_q_tot, tot_m=prefetched[2] if len(prefetched) > 2 else None)
         elif two_streams:
             origin = torch.cuda.current_stream(dev)
             if getattr(self, "_target_stream", None) is None:
@@ -476,7 +477,7 @@ class QMixLearner:
             eval_q_tot = eval_forward()
         return self._finish_update(st, T, eval_q_tot, target_q_tot)
 
-    def _finish_update(self, st, T, eval_q_tot, target_q_tot):
+    def _finish_update(self, st, T, eval_q_tot, target_q_tot, tot_m=None):
         # loss over eval steps 0..T-2 against targets built from target steps 1..T-1 (qmix.py:155,190-194)
         for p in self.params:
             p.grad = None
@@ -484,15 +485,40 @@ class QMixLearner:
             # the loss kernel also produces dL/dQ_tot: it seeds the backward pass directly (no ones-fill / multiply).
             # (Measured and dropped: the loss inside the eval mixer's backward launch — its loads and reductions in front of
             # the kernel's chain cost the 7 us the separate launch does: 26.2 vs 7.5 + 17.8 us.)
-            loss, eval_mean, target_mean, gy, self._last_stats4 = ops.td_loss_and_grad(
-                eval_q_tot, target_q_tot, st["reward"], st["terminated"], st["filled"], self.args.gamma, T - 1, 1)
+            stats_done = None
+            if (tot_m is not None and os.environ.get("MACJD_TD_GRAD_IN_MIXER", "1") != "0"
+                    and ops.fused_mixer_backward_will_run(eval_q_tot)):
+                # pipelined update: the batch's mask sum was computed behind its gather, so the eval mixer's backward
+                # launch forms dL/dQ_tot itself (5 loads per row) and the loss launch leaves the serial chain: it still runs
+                # — for the logged sums — on the side stream, ordered before the optimiser writes the gradient norm into
+                # the same row
+                origin = torch.cuda.current_stream(eval_q_tot.device)
+                ts = self._target_stream
+                head_done = torch.cuda.Event()
+                head_done.record(origin)
+                with torch.cuda.stream(ts):
+                    ts.wait_event(head_done)
+                    loss, eval_mean, target_mean, _, self._last_stats4 = ops.td_loss_and_grad(
+                        eval_q_tot, target_q_tot, st["reward"], st["terminated"], st["filled"], self.args.gamma, T - 1, 1)
+                    stats_done = torch.cuda.Event()
+                    stats_done.record(ts)
+                gy = ops.td_grad_in_mixer_backward(eval_q_tot, target_q_tot, st["reward"], st["terminated"], st["filled"],
+                                                   self.args.gamma, T - 1, 1, tot_m)
+            else:
+                loss, eval_mean, target_mean, gy, self._last_stats4 = ops.td_loss_and_grad(
+                    eval_q_tot, target_q_tot, st["reward"], st["terminated"], st["filled"], self.args.gamma, T - 1, 1)
             # the weight gradients: one grouped launch pair after the chain, written into the flat gradient vector
             # (single process: the LayerNorm-parameter launch behind the grouped products is held back and evaluated
             # inside the optimiser step's squared-norm launch — with more ranks the all-reduce needs it done first)
             hold = self._flat_param is not None and self._world_size() <= 1 and os.environ.get("MACJD_LN_IN_SQNORM", "1") != "0"
             with ops.deferred_wgrad(grad_dst=getattr(self, "_grad_dst", None), hold_lnparam=hold) as dw:
                 eval_q_tot.backward(gy)
+            assert ops._PENDING_TD is None, "the fused mixer's backward did not take the TD loss's inputs"
             self._held_ln = dw.held
+            if stats_done is not None:
+                torch.cuda.current_stream(eval_q_tot.device).wait_event(stats_done)
+                for t_ in (self._last_stats4,):
+                    t_.record_stream(torch.cuda.current_stream(eval_q_tot.device))
         else:
             loss, eval_mean, target_mean = ops.td_loss_full(eval_q_tot, target_q_tot, st["reward"], st["terminated"],
                                                             st["filled"], self.args.gamma, T - 1, 1)
@@ -679,13 +705,14 @@ class QMixLearner:
                 with torch.cuda.stream(ts), torch.no_grad():
                     ops.sample_episodes(self._g_idx, self._g_n_stored, self._g_draws, self._sampler_seed())
                     ops.gather_rows(self._g_idx, srcs, [dst[k] for k in keys])
+                    tot_m = ops.td_mask_sum(dst["filled"], self._g_T - 1)     # the loss's only global sum the gradient needs
                     ev_g = torch.cuda.Event()
                     ev_g.record(ts)
                     h, ps = ops.gru_sequence_from_obs(buffer.buffers["obs"], self._g_idx, agents, self._g_B, self.n_agents,
                                                       self._g_T + 1, with_actor=True)
                     ev_s = torch.cuda.Event()
                     ev_s.record(ts)
-                return (([h[0], h[0]] if shared else h), ([ps[0], ps[0]] if shared else ps), (ev_g, ev_s))
+                return (([h[0], h[0]] if shared else h), ([ps[0], ps[0]] if shared else ps), (ev_g, ev_s, tot_m))
 
             with torch.cuda.graph(gm, pool=self._graph_a.pool(), capture_error_mode="thread_local"):
                 nxt_batch = None

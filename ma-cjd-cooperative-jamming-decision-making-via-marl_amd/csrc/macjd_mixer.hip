@@ -252,8 +252,14 @@ __global__ void __launch_bounds__(256) mixer_fused_forward_kernel(const macjd_mi
 }
 
 // Backward (see the header): recompute the second layers from `act`, tail gradients, transposed second layers.
-template <int J>
-__global__ void __launch_bounds__(256) mixer_fused_backward_kernel(const macjd_mixerf_io io) {
+// TD = the gradient of the learner's TD loss w.r.t. this mixer's output is formed HERE instead of being read from io.gy
+// (macjd_mixer_fused_backward_td): row m = (b, t) gets scale * mask * (y - (r + gamma (1 - term) tq)) for t < Tm1 and 0
+// otherwise — td_loss_kernel's own expression, with scale = 2 / *tot_m from a launch that summed the batch's mask earlier
+// (macjd_td_mask_sum: it needs the gathered batch only, so it runs long before).  Five loads per row, no reduction: the
+// loss launch leaves the update's serial chain (its logged sums are computed off the chain by macjd_td_loss).
+template <int J, bool TD = false>
+__global__ void __launch_bounds__(256) mixer_fused_backward_kernel(const macjd_mixerf_io io, const macjd_tdloss_io td,
+                                                                    const float* __restrict__ tot_m) {
     constexpr int LDG = J * MX_EM + 8;      // pitch of g_w1raw in LDS (= 8 mod 16)
     constexpr int LDF = MX_EM + 8;
     constexpr int KQ1 = J * MX_EM / 16;     // quads of the transposed hyper_w_1.2 product
@@ -304,13 +310,28 @@ __global__ void __launch_bounds__(256) mixer_fused_backward_kernel(const macjd_m
 #pragma unroll
     for (int i = 0; i < 4; ++i) wvo[i] = io.wV2[(threadIdx.x + 256 * i) & (MX_EM - 1)];   // for the V head's outer product
     const float bV2 = io.bV2[0];
-    const float gy_li = io.gy[(m0 + li < io.M) ? m0 + li : io.M - 1];
+    auto load_gy = [&](const int64_t mc) -> float {
+        if constexpr (TD) {
+            const int cols = (int)td.gy_cols;
+            const int b = (int)(mc / cols), t = (int)(mc - (int64_t)b * cols);
+            const int tc = t < td.Tm1 ? t : td.Tm1 - 1;     // clamped: no branch around the loads
+            const float term = td.terminated[b * td.t_sb + tc * td.t_st] ? 1.0f : 0.0f;
+            const float mk = td.filled[b * td.f_sb + tc * td.f_st] ? 1.0f : 0.0f;
+            const float target = td.reward[b * td.r_sb + tc * td.r_st] + td.gamma * (1.0f - term) * td.tq[b * td.tq_sb + tc];
+            const float scale = 2.0f / tot_m[0];
+            const float gv = scale * mk * (td.y[b * td.y_sb + tc] - target);
+            return t < td.Tm1 ? gv : 0.0f;
+        } else {
+            return io.gy[mc];
+        }
+    };
+    const float gy_li = load_gy((m0 + li < io.M) ? m0 + li : io.M - 1);
     float qv[4][J], gyv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int64_t m = m0 + 4 * g + r;
         const int64_t mc = m < io.M ? m : io.M - 1;   // clamped (no branch around a load); rows past M are never stored
-        gyv[r] = io.gy[mc];
+        gyv[r] = load_gy(mc);
 #pragma unroll
         for (int j = 0; j < J; ++j) qv[r][j] = io.q[mc * J + j];
     }
@@ -420,7 +441,7 @@ __global__ void __launch_bounds__(256) mixer_fused_backward_kernel(const macjd_m
     }
 }
 
-static int mixerf_check(const macjd_mixerf_io* io, bool backward) {
+static int mixerf_check(const macjd_mixerf_io* io, bool backward, bool gy_from_td = false) {
     if (!io) return set_err(MACJD_EINVAL, "%s", "macjd_mixer_fused: NULL io");
     if (!macjd_mixer_fused_supported(io->J, io->S, io->Hh, io->Em))
         return set_err(MACJD_EUNSUPPORTED, "%s", "macjd_mixer_fused: unsupported J / S / Hh / Em (see include/macjd_nets.h)");
@@ -431,7 +452,7 @@ static int mixerf_check(const macjd_mixerf_io* io, bool backward) {
             return set_err(MACJD_EINVAL, "%s", "macjd_mixer_fused_forward: NULL input / output or bad s_ld");
         if (io->save && (!io->sn || !io->xhat || !io->act))
             return set_err(MACJD_EINVAL, "%s", "macjd_mixer_fused_forward: save needs sn / xhat / act");
-    } else if (!io->act || !io->gy || !io->gq || !io->gout1 || !io->g_w1raw || !io->g_wfraw || !io->g_v) {
+    } else if (!io->act || (!io->gy && !gy_from_td) || !io->gq || !io->gout1 || !io->g_w1raw || !io->g_wfraw || !io->g_v) {
         return set_err(MACJD_EINVAL, "%s", "macjd_mixer_fused_backward: NULL input / output");
     }
     if (((uintptr_t)io->act) & 15)   // (weights may sit anywhere in a flat parameter vector: their fragment loads assume 4 bytes)
@@ -474,10 +495,31 @@ extern "C" int macjd_mixer_fused_backward(const macjd_mixerf_io* io, void* hip_s
     if (io->M == 0) return MACJD_OK;
     const dim3 grid((unsigned)((io->M + 15) / 16)), block(256);
     hipStream_t s = (hipStream_t)hip_stream;
-    if (io->J == 2) hipLaunchKernelGGL((mixer_fused_backward_kernel<2>), grid, block, 0, s, *io);
-    else if (io->J == 3) hipLaunchKernelGGL((mixer_fused_backward_kernel<3>), grid, block, 0, s, *io);
-    else hipLaunchKernelGGL((mixer_fused_backward_kernel<6>), grid, block, 0, s, *io);
+    const macjd_tdloss_io none{};
+    if (io->J == 2) hipLaunchKernelGGL((mixer_fused_backward_kernel<2>), grid, block, 0, s, *io, none, nullptr);
+    else if (io->J == 3) hipLaunchKernelGGL((mixer_fused_backward_kernel<3>), grid, block, 0, s, *io, none, nullptr);
+    else hipLaunchKernelGGL((mixer_fused_backward_kernel<6>), grid, block, 0, s, *io, none, nullptr);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_mixer_fused_backward: %s", hipGetErrorString(err));
+    return MACJD_OK;
+}
+
+extern "C" int macjd_mixer_fused_backward_td(const macjd_mixerf_io* io, const macjd_tdloss_io* td, const float* tot_m,
+                                             void* hip_stream) {
+    using namespace macjd;
+    const int rc = mixerf_check(io, true, true);
+    if (rc != MACJD_OK) return rc;
+    if (!td || !tot_m || td->B < 1 || td->Tm1 < 1 || !td->y || !td->tq || !td->reward || !td->terminated || !td->filled)
+        return set_err(MACJD_EINVAL, "%s", "macjd_mixer_fused_backward_td: bad TD-loss argument");
+    if (td->gy_cols < td->Tm1 || (int64_t)td->B * td->gy_cols != io->M || td->y_sb < td->Tm1 || td->tq_sb < td->Tm1)
+        return set_err(MACJD_EINVAL, "%s", "macjd_mixer_fused_backward_td: rows must be B x gy_cols with gy_cols >= Tm1");
+    if (io->M == 0) return MACJD_OK;
+    const dim3 grid((unsigned)((io->M + 15) / 16)), block(256);
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (io->J == 2) hipLaunchKernelGGL((mixer_fused_backward_kernel<2, true>), grid, block, 0, s, *io, *td, tot_m);
+    else if (io->J == 3) hipLaunchKernelGGL((mixer_fused_backward_kernel<3, true>), grid, block, 0, s, *io, *td, tot_m);
+    else hipLaunchKernelGGL((mixer_fused_backward_kernel<6, true>), grid, block, 0, s, *io, *td, tot_m);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_mixer_fused_backward_td: %s", hipGetErrorString(err));
     return MACJD_OK;
 }

@@ -805,6 +805,37 @@ __global__ void __launch_bounds__(1024) td_loss_kernel(const macjd_tdloss_io io)
 
 }  // namespace macjd
 
+namespace macjd {
+// sum of the loss mask of a batch (the tot_m of td_loss_kernel; sums of 0 / 1 are exact in any order): what
+// macjd_mixer_fused_backward_td needs of the loss's global sums, from the gathered batch alone
+__global__ void __launch_bounds__(1024) td_mask_sum_kernel(const macjd_tdloss_io io, float* __restrict__ out) {
+    __shared__ float s_w[16];
+    const int M = io.B * io.Tm1;
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < M; i += blockDim.x) {
+        const int b = i / io.Tm1, t = i - b * io.Tm1;
+        s += io.filled[b * io.f_sb + t * io.f_st] ? 1.0f : 0.0f;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = (threadIdx.x < (blockDim.x >> 6)) ? s_w[threadIdx.x] : 0.0f;
+        t = wave_sum(t);
+        if (threadIdx.x == 0) out[0] = t;
+    }
+}
+}  // namespace macjd
+
+extern "C" int macjd_td_mask_sum(const macjd_tdloss_io* io, float* out, void* hip_stream) {
+    using namespace macjd;
+    if (!io || !out || io->B < 1 || io->Tm1 < 1 || !io->filled) return set_nets_err(MACJD_EINVAL, "macjd_td_mask_sum: bad argument");
+    hipLaunchKernelGGL(td_mask_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, *io, out);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_nets_err(MACJD_EDEVICE, hipGetErrorString(err));
+    return MACJD_OK;
+}
+
 extern "C" int macjd_td_loss(const macjd_tdloss_io* io, void* hip_stream) {
     using namespace macjd;
     if (!io || io->B < 1 || io->Tm1 < 1) return set_nets_err(MACJD_EINVAL, "macjd_td_loss: bad B / Tm1");

@@ -555,8 +555,15 @@ class _FusedMixer(torch.autograd.Function):
         io = _mixerf_io(q, None, params)
         io.act, io.gy, io.gq, io.gout1 = act.data_ptr(), gy.data_ptr(), gq.data_ptr(), gout1.data_ptr()
         io.g_w1raw, io.g_wfraw, io.g_v = g_w1.data_ptr(), g_wf.data_ptr(), g_v.data_ptr()
+        global _PENDING_TD
+        pend, _PENDING_TD = _PENDING_TD, None
         with torch.cuda.device(dev):
-            _native.check(lib.macjd_mixer_fused_backward(ctypes.byref(io), _stream(q)), "macjd_mixer_fused_backward")
+            if pend is not None:   # the loss's gradient is formed in this launch: `gy` is a placeholder (td_grad_in_mixer_backward)
+                assert pend[2] == M, "td_grad_in_mixer_backward: the loss rows are not this mixer's rows"
+                _native.check(lib.macjd_mixer_fused_backward_td(ctypes.byref(io), ctypes.byref(pend[0]), pend[3].data_ptr(),
+                                                                _stream(q)), "macjd_mixer_fused_backward_td")
+            else:
+                _native.check(lib.macjd_mixer_fused_backward(ctypes.byref(io), _stream(q)), "macjd_mixer_fused_backward")
         nd = ctx.needs_input_grad
         # weight / bias gradients: split-K products of the matrices the kernel wrote (recorded inside deferred_wgrad)
         gW1, gb1 = linear_wgrad(gout1, sn, want_bias=True, w_key=grad_key(w_cat), b_key=ctx.keys["b_cat"])
@@ -780,6 +787,57 @@ def td_loss_and_grad(y_full, tq_full, reward, terminated, filled, gamma, Tm1, tq
     with torch.no_grad():
         _, stats = _TdLossHip.apply(y_full, tq_full, reward, terminated, filled, gamma, Tm1, tq_off)
     return stats[0], stats[1], stats[2], stats.saved_gy, stats
+
+
+def td_mask_sum(filled, Tm1):
+    """float32 [1]: the number of loss-carrying steps of a batch, sum(filled[:, :Tm1]) — the one global quantity the TD
+    loss's gradient needs (``td_grad_in_mixer_backward``).  ``filled`` [B, >= Tm1, 1] bool on a HIP device."""
+    lib = _native.load()
+    out = torch.empty(1, dtype=torch.float32, device=filled.device)
+    io = _native.TdLossIO()
+    io.B, io.Tm1 = filled.shape[0], int(Tm1)
+    io.filled, io.f_sb, io.f_st = filled.data_ptr(), filled.stride(0), filled.stride(1)
+    with torch.cuda.device(filled.device):
+        _native.check(lib.macjd_td_mask_sum(ctypes.byref(io), out.data_ptr(), _stream(filled)), "macjd_td_mask_sum")
+    return out
+
+
+_PENDING_TD = None   # TD-loss inputs waiting for the fused mixer's backward launch (td_grad_in_mixer_backward)
+
+
+def fused_mixer_backward_will_run(y_full) -> bool:
+    """``y_full`` is the output of the fused mixer node (possibly behind views): its backward is ONE launch that can form
+    the TD loss's gradient itself (macjd_mixer_fused_backward_td)."""
+    fn = getattr(y_full, "grad_fn", None)
+    for _ in range(4):
+        if fn is None:
+            return False
+        if type(fn).__name__.startswith("_FusedMixer"):
+            return True
+        nxt = [f for f, _ in fn.next_functions if f is not None]
+        if len(nxt) != 1:
+            return False
+        fn = nxt[0]
+    return False
+
+
+def td_grad_in_mixer_backward(y_full, tq_full, reward, terminated, filled, gamma, Tm1, tq_off, tot_m):
+    """Arrange for the fused mixer's backward launch (started by ``y_full.backward(placeholder)``, placeholder = the return
+    value) to form dL/dy of the TD loss itself from the loss's inputs and ``tot_m`` (``td_mask_sum``): no loss launch in
+    front of the backward pass.  The logged statistics are the caller's business (``td_loss_and_grad`` off the chain)."""
+    global _PENDING_TD
+    B, Ty = y_full.shape[0], y_full.shape[1]
+    yc, tqc = y_full.detach().float().contiguous(), tq_full.detach().float().contiguous()
+    io = _native.TdLossIO()
+    io.B, io.Tm1, io.gamma = B, int(Tm1), float(gamma)
+    io.y, io.y_sb = yc.data_ptr(), Ty
+    io.tq, io.tq_sb = tqc.data_ptr() + 4 * int(tq_off), tqc.shape[1]
+    io.gy, io.gy_sb, io.gy_cols = None, Ty, Ty
+    io.reward, io.r_sb, io.r_st = reward.data_ptr(), reward.stride(0), reward.stride(1)
+    io.terminated, io.t_sb, io.t_st = terminated.data_ptr(), terminated.stride(0), terminated.stride(1)
+    io.filled, io.f_sb, io.f_st = filled.data_ptr(), filled.stride(0), filled.stride(1)
+    _PENDING_TD = (io, (yc, tqc, reward, terminated, filled, tot_m), B * Ty, tot_m)
+    return torch.empty((B, Ty, 1), dtype=torch.float32, device=yc.device)   # never read
 
 
 def td_loss(y, tq, reward, terminated, filled, gamma):
