@@ -33,7 +33,7 @@ import torch
 import torch.nn.functional as F
 import torch.optim as optim
 
-from .. import ops
+from .. import hipgraph, ops
 from .networks import QMixer
 
 
@@ -579,31 +579,33 @@ class QMixLearner:
         target syncs (in-place ``load_state_dict``) and new episodes are seen by the replayed graphs."""
         if self.device.type != "cuda":
             raise RuntimeError("enable_graphs needs the learner on a HIP device")
+        self.release_graphs()   # a re-capture destroys the previous graphs first, explicitly and at a quiet point
+        same_buffer = getattr(self, "_g_buffer", None) is buffer
         self._g_buffer, self._g_B, self._g_T = buffer, int(batch_size), int(buffer.episode_limit)
         # static observations in every stored episode (see _forward_backward_full): baked into the captured launches
         self._g_obs_static = bool(getattr(buffer, "obs_static", False)) and os.environ.get("MACJD_LEARNER_STATIC_OBS", "1") != "0"
-        # the actor rows ride in the scan launch where the one-launch Double-DQN step consumes them per sequence (the
-        # benchmark's sizes); sizes without that launch keep the actor chain as its own launch on the origin stream — the
-        # arrangement their graphs were validated with (the other one, with the rows expanded behind the join for the
-        # two-launch form, showed host faults inside hipGraphLaunch in two of ~15 full test runs)
-        self._g_actor_in_scan = os.environ.get("MACJD_ACTOR_IN_SCAN", "1") != "0" and \
-            (os.environ.get("MACJD_ACTOR_IN_SCAN") == "1" or
-             (os.environ.get("MACJD_FUSED_DOUBLEQ", "1") != "0" and
-              ops.qhead_double_q_fused_supported(self._flat_param if self._flat_param is not None else buffer.buffers["obs"],
-                                                 int(self.args.rnn_hidden_dim), int(self.n_actions))))
+        # the actor rows of each sequence's observation ride in the scan launch's prologue (MACJD_ACTOR_IN_SCAN=0: the
+        # actor chain as its own launch on the origin stream)
+        self._g_actor_in_scan = os.environ.get("MACJD_ACTOR_IN_SCAN", "1") != "0"
         self._g_scan_from_ring = self._g_obs_static and os.environ.get("MACJD_SCAN_FROM_RING", "1") != "0" \
             and int(buffer.buffers["obs"].shape[-1]) <= 3 * int(self.args.rnn_hidden_dim)
-        self._g_idx = torch.zeros(self._g_B, dtype=torch.int64, device=self.device)
+        # (a re-capture with the same batch size keeps the index tensor: the batch the last update drew for the next one is
+        # still in it, so the sequence of updates continues as if nothing had been re-captured)
+        prev_idx = getattr(self, "_g_idx", None)
+        keep_idx = same_buffer and prev_idx is not None and prev_idx.numel() == self._g_B and prev_idx.device == self.device
+        self._g_idx = prev_idx if keep_idx else torch.zeros(self._g_B, dtype=torch.int64, device=self.device)
         # The batch of an update whose caller passes no indices is drawn ON THE DEVICE by the previous update's last
         # launch (ops.sample_episodes: uniform without replacement over the stored episodes, like the reference's
         # np.random.choice in buffer.sample): no index upload between two replayed updates — that copy and its two
         # stream-order hops were ~10 us of a ~190 us step.  MACJD_DEVICE_SAMPLER=0: host draw + upload.
         self._g_dev_sampler = self._flat_param is not None and os.environ.get("MACJD_DEVICE_SAMPLER", "1") != "0"
-        self._g_n_stored = torch.zeros(1, dtype=torch.int32, device=self.device)
+        if not keep_idx:
+            self._g_n_stored = torch.zeros(1, dtype=torch.int32, device=self.device)
         if getattr(self, "_g_draws", None) is None:   # draws made so far (the sampler's counter; survives a re-capture)
             self._g_draws = torch.full((1,), int(getattr(self, "_resume_draws", 0)), dtype=torch.int64, device=self.device)
-        self._g_pop_seen = None       # (store_count, current_size) the device-side population scalar / last draw refer to
-        self._g_idx_fresh = False     # _g_idx holds a device draw from the current population that no update has used yet
+        if not keep_idx:
+            self._g_pop_seen = None       # (store_count, current_size) the device-side population scalar / last draw refer to
+            self._g_idx_fresh = False     # _g_idx holds a device draw from the current population that no update has used yet
         self._g_idx_ring = [(torch.zeros(self._g_B, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(8)]
         if buffer.current_size < 1:
             raise RuntimeError("enable_graphs: the replay buffer is empty")
@@ -659,8 +661,7 @@ class QMixLearner:
         # a single process has no all-reduce between the two halves: one graph, one launch per update
         # (force_two_graphs: the layout every rank of a multi-GPU job runs, for single-process tests)
         self._g_single = self._world_size() <= 1 and not force_two_graphs
-        # thread_local: other threads (RCCL's watchdog polls events) may touch the runtime during capture
-        with torch.cuda.graph(self._graph_a, capture_error_mode="thread_local"):
+        with hipgraph.capture(self._graph_a):
             self._g_out_a = body_a()
             # the four logged scalars of an update end up in ONE static [4] tensor: the loss kernel writes (loss,
             # mean Q_tot, mean target, mask sum) and the optimiser step then overwrites the unused mask sum with the
@@ -673,7 +674,7 @@ class QMixLearner:
             if self._g_single:
                 self._g_out_b = self._clip_and_step(sample_next=nxt)
         if not self._g_single:
-            with torch.cuda.graph(self._graph_b, pool=self._graph_a.pool(), capture_error_mode="thread_local"):
+            with hipgraph.capture(self._graph_b, pool=self._graph_a.pool()):
                 self._g_out_b = self._clip_and_step(sample_next=nxt)
         # K consecutive updates as ONE graph (train_from_buffer_many): between two replayed graphs the stream pays a
         # launch-to-launch hand-over (~20 us here) that an edge inside a graph does not.  Needs the device-side draw (every
@@ -714,7 +715,7 @@ class QMixLearner:
                     ev_s.record(ts)
                 return (([h[0], h[0]] if shared else h), ([ps[0], ps[0]] if shared else ps), (ev_g, ev_s, tot_m))
 
-            with torch.cuda.graph(gm, pool=self._graph_a.pool(), capture_error_mode="thread_local"):
+            with hipgraph.capture(gm, pool=self._graph_a.pool()):
                 nxt_batch = None
                 for k_upd in range(K):
                     last = k_upd == K - 1
@@ -743,6 +744,26 @@ class QMixLearner:
         self._g_shared_body = self._body_is_shared()   # baked into the captured launches
         assert self._g_obs_static == (bool(getattr(buffer, "obs_static", False)) and os.environ.get("MACJD_LEARNER_STATIC_OBS", "1") != "0")
         self._graphs_ready = True
+
+    def release_graphs(self):
+        """Destroy the captured update graphs and everything that lives in their memory pool (staging tensors, static
+        outputs, the side stream's events) — explicitly, with the device idle, the grouped graph and graph B (captured
+        into graph A's pool) before graph A.  ``enable_graphs`` calls it before it captures again; call it yourself to
+        return the pool's memory.  Afterwards ``train_from_buffer`` raises until ``enable_graphs`` ran again."""
+        graphs = []
+        m = getattr(self, "_g_multi", None)
+        if m is not None:
+            graphs.append(m[1])
+        graphs += [getattr(self, "_graph_b", None), getattr(self, "_graph_a", None)]
+        self._graphs_ready = False
+        self._g_multi = None
+        self._graph_a = self._graph_b = None
+        self._graph_body_a = None
+        self._g_out_a = self._g_out_b = self._g_stats4 = self._last_stats4 = self._held_ln = None
+        if self._flat_param is not None and any(g is not None for g in graphs):
+            # the gradient norm was re-pointed at a static output row of the pool being released
+            self._grad_norm = torch.zeros((), dtype=torch.float32, device=self._flat_param.device)
+        hipgraph.destroy(graphs, self.device)
 
     def train_from_buffer(self, indices=None, sync_stats=True, stats_row=None):
         """Sample ``batch_size`` whole episodes (np.random.choice like the reference's buffer) and update.
@@ -786,12 +807,12 @@ class QMixLearner:
             slot.numpy()[:] = indices
             self._g_idx.copy_(slot, non_blocking=True)
             ev.record()
-        self._graph_a.replay()
+        hipgraph.replay(self._graph_a, self.device)
         # (the replayed update ends with the draw of the next batch from the population the device scalar names)
         self._g_idx_fresh = self._g_dev_sampler and (buf.store_count, buf.current_size) == self._g_pop_seen
         if not self._g_single:
             self._allreduce_grads()
-            self._graph_b.replay()
+            hipgraph.replay(self._graph_b, self.device)
         self._after_step()
         loss, ev, tg = self._g_out_a
         if stats_row is not None and not sync_stats and self._g_stats4 is not None:
@@ -828,7 +849,7 @@ class QMixLearner:
                     and (not self._g_shared_body or self._body_is_shared())):
                 self._device_draw_ready(buf)
                 self.train_step += m[0]
-                m[1].replay()
+                hipgraph.replay(m[1], self.device)
                 self._g_idx_fresh = (buf.store_count, buf.current_size) == self._g_pop_seen
                 self._after_step()
                 if stats_out is not None:

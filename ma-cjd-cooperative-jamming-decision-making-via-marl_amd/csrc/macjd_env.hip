@@ -1196,6 +1196,9 @@ static int env_step_timed_impl(const macjd_scenario* s, const macjd_step_io* io,
     }
     (void)hipEventRecord(t1, stream);
     err = hipEventSynchronize(t1);
+    // the graph is destroyed with its stream drained (the runtime defers the release of a launched graph to the launch
+    // stream's next synchronisation point; that stream is destroyed right below)
+    if (priv) (void)hipStreamSynchronize(priv);
     if (exec) (void)hipGraphExecDestroy(exec);
     if (graph) (void)hipGraphDestroy(graph);
     if (priv) (void)hipStreamDestroy(priv);

@@ -283,9 +283,11 @@ class BatchedEpisodeRunner:
         with torch.cuda.stream(s):  # warm-up outside capture
             self._rollout_body(device_schedule=True, n_steps=n)
         torch.cuda.current_stream(dev).wait_stream(s)
+        from .. import hipgraph
+        if n in self._graphs:   # re-capture of the same length: the old graph goes first, explicitly
+            hipgraph.destroy([self._graphs.pop(n)], dev)
         graph = torch.cuda.CUDAGraph()
-        # thread_local: other threads (RCCL's watchdog polls events) may touch the runtime during capture
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        with hipgraph.capture(graph):
             self._rollout_body(device_schedule=True, n_steps=n)
         self._graphs[n] = graph
         if n == T:
@@ -294,6 +296,14 @@ class BatchedEpisodeRunner:
             env_ep.copy_(env_ep0)
         self.t_env, self._ep = t_env0, ep0
         self.mac.device_schedule = None
+
+    def release_graphs(self):
+        """Destroy the captured rollout graphs explicitly, with the device idle (see hipgraph.py); ``run`` then falls back
+        to the fused / step-by-step rollout until ``enable_graph`` is called again."""
+        from .. import hipgraph
+        graphs = list((getattr(self, "_graphs", None) or {}).values())
+        self._graphs, self._graph = None, None
+        hipgraph.destroy(list(reversed(graphs)), self.device)
 
     def _rollout_body(self, device_schedule=False, n_steps=None):
         T = self.episode_limit if n_steps is None else n_steps
@@ -315,7 +325,8 @@ class BatchedEpisodeRunner:
         self._upload_eps_schedule(eps)
         self._ep += 1
         self._ctr_base.fill_(self._ep * (T + 1))
-        self._graphs[n].replay()
+        from .. import hipgraph
+        hipgraph.replay(self._graphs[n], self.device)
         self.t_env += n
 
     # ---- whole-episode launches: the agent's T steps as one kernel, the env's T steps as another ----

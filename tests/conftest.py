@@ -31,19 +31,30 @@ def pytest_collection_modifyitems(config, items):
 
 
 def pytest_sessionstart(session):
-    """HIP graphs captured by a test stay alive until the session ends.  Destroying a graph (and releasing its private
-    memory pool) while later tests capture and replay their own has produced host faults inside hipGraphLaunch on this
-    ROCm stack — intermittently with Python's own collector, deterministically when a fixture forced the collection
-    after every test.  A training process never destroys its graphs mid-run; the test session now does not either."""
-    if not _has_gpu():
+    if _has_gpu() and os.environ.get("MACJD_SEGV_TRACE"):   # diagnostic: native backtrace of a host fault (scripts/segv_trace.c)
+        import ctypes
+        ctypes.CDLL(os.environ["MACJD_SEGV_TRACE"]).segv_trace_install()
+
+
+@pytest.fixture(autouse=True)
+def _teardown_graphs_after_every_gpu_test(request):
+    """Every GPU test's HIP graphs are destroyed and their memory pools returned to the driver right after the test.
+    This is the arrangement under which, in round 2, a later graph replay faulted deterministically inside
+    hipGraphLaunch (the runtime's parallel-stream selection reads past its vector once destroyed graphs have left the
+    hardware-queue reference counts uneven); with the replays launched from the high-priority stream
+    (macjd_amd/hipgraph.py) the suite has to pass under exactly this stress.  MACJD_TEST_GRAPH_TEARDOWN=0 switches it off."""
+    if os.environ.get("MACJD_TEST_GRAPH_TEARDOWN", "1") == "0" or "gpu" not in request.keywords or not _has_gpu():
+        yield
         return
+    import gc
     import torch
-    keep = []
-    orig = torch.cuda.CUDAGraph.capture_end
-
-    def capture_end(self):
-        orig(self)
-        keep.append(self)
-
-    torch.cuda.CUDAGraph.capture_end = capture_end
-    session.config._macjd_graphs_kept = keep
+    gc.collect()
+    gc.disable()
+    try:
+        yield
+    finally:
+        torch.cuda.synchronize()
+        gc.enable()
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()

@@ -1714,6 +1714,65 @@ def test_updates_grouped_into_one_graph_equal_single_updates():
         assert torch.equal(a, b), k_
 
 
+def test_learner_graphs_recaptured_and_released_in_one_process():
+    """enable_graphs() is meant to be called again mid-run (after the buffer lost its static-observation flag, the agent
+    body changed, another grouping is wanted): every call destroys the previous graphs first (QMixLearner.release_graphs:
+    device idle, grouped graph and graph B before graph A), and the re-captured learner continues the SAME sequence of
+    updates — weights bitwise equal to a learner captured once.  Other learners' multi-branch graphs, created and destroyed
+    in between, must not disturb it: this is the history (graph streams created and destroyed, their hardware-queue
+    references returned) under which round 2's replay faulted inside hipGraphLaunch (macjd_amd/hipgraph.py)."""
+    from macjd_amd.core.mac import BasicMAC
+    from macjd_amd.core.qmix import QMixLearner
+    from macjd_amd.utils.replay_buffer import EpisodeReplayBuffer
+    from tests_golden_helpers import synthetic_batch
+    g, d = load("3j4r_h64")
+    T, N, B = 100, 48, 32
+
+    def build(k):
+        args = _gpu_args(d, episode_limit=T, buffer_size=N, batch_size=B, target_update_interval=5, lr=1e-3)
+        with quiet():
+            mac = BasicMAC(d["S"], args)
+            mac.load_state(sd_from(g, "g5_agent0."))
+            learner = QMixLearner(mac, args)
+            buf = EpisodeReplayBuffer(args)
+        learner.eval_qmix_net.load_state_dict(sd_from(g, "g5_mixer0."))
+        learner._update_targets()
+        full = synthetic_batch(np.random.default_rng(9), args, N, T)
+        for kk, v in buf.buffers.items():
+            v.copy_(torch.as_tensor(full[kk]).to(v.dtype))
+        buf.current_size, buf.current_index = N, 0
+        buf.episode_lengths[:] = T
+        learner.enable_graphs(buf, B, updates_per_graph=k)
+        return mac, learner, buf
+
+    mac_r, ref, _ = build(2)
+    mac_c, cut, buf_c = build(2)
+    ref.train_from_buffer_many(9)
+    cut.train_from_buffer_many(3)
+    # other learners come and go in between (their graphs are destroyed explicitly or by the collector)
+    for k in (1, 4):
+        _, other, _ = build(k)
+        other.train_from_buffer_many(4)
+        other.release_graphs()
+        with pytest.raises(RuntimeError, match="enable_graphs"):
+            other.train_from_buffer()
+        del other
+    cut.enable_graphs(buf_c, B, updates_per_graph=4)      # re-capture, another grouping
+    assert cut._g_multi[0] == 4
+    cut.train_from_buffer_many(2)
+    cut.enable_graphs(buf_c, B, updates_per_graph=1)      # ... and again, single updates
+    assert cut._g_multi is None
+    cut.train_from_buffer_many(4)
+    assert cut.train_step == ref.train_step == 9 and int(cut._g_draws.item()) == int(ref._g_draws.item())
+    for (k_, a), b in zip(mac_r.agent.state_dict().items(), mac_c.agent.state_dict().values()):
+        assert torch.equal(a, b), k_
+    for (k_, a), b in zip(ref.eval_qmix_net.state_dict().items(), cut.eval_qmix_net.state_dict().values()):
+        assert torch.equal(a, b), k_
+    # eager updates keep working after the graphs are gone
+    cut.release_graphs()
+    assert np.isfinite(cut.train(buf_c.sample(B), {})["loss"])
+
+
 @pytest.mark.parametrize("deferred", [False, True])
 @pytest.mark.parametrize("N,K,Hd", [(9696, 74, 64), (1500, 33, 20)])
 def test_relu_backward_operand_formed_inside_the_weight_gradient_kernel(N, K, Hd, deferred, monkeypatch):
