@@ -48,6 +48,7 @@ def algorithmic_bytes_per_env_step(J, R, uniforms_supplied, info_outputs=True):
 
 
 def dist_setup(n_gpus):
+    import macjd_amd  # noqa: F401  (first: reserves the graph-launch hardware queue before the HIP runtime starts)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))

@@ -16,3 +16,9 @@ Sub-packages mirror the reference's module layout for the hot path so that the r
     macjd_amd.runners.episode_runner   EpisodeRunner, BatchedEpisodeRunner
 """
 __version__ = "0.1.0"
+
+# One of the GPU's four hardware queues is set aside for HIP-graph launches (hipgraph.py, DESIGN.md 4.8); this has to
+# happen before the HIP runtime initialises, i.e. before the first torch.cuda call of the process.
+from . import hipgraph as _hipgraph  # noqa: E402
+
+_hipgraph.reserve_launch_queue()

@@ -9,6 +9,9 @@ for p in (REPO, os.path.join(REPO, "tests")):
         sys.path.insert(0, p)
 
 
+import macjd_amd  # noqa: E402,F401  (before the first torch.cuda call: reserves the graph-launch hardware queue, hipgraph.py)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

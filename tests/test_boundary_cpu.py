@@ -163,3 +163,21 @@ def test_edge_scenario_flags():
     assert den[0, 0] < 0            # jammer 0 sits on radar 0
     assert flg[2, 2] == 1           # Python-float (weak) denominator
     assert flg.sum() == 1 and (den[den >= 0] > 0).all()
+
+
+def test_graph_launch_queue_reservation_rules():
+    """macjd_amd/hipgraph.py: importing the package before the HIP runtime starts reserves one of the four hardware queues
+    for graph launches (GPU_MAX_HW_QUEUES=3 -> replays go through the high-priority stream); a user setting that leaves no
+    room selects the other arrangement (replays on the caller's stream, captured graphs never destroyed)."""
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); import macjd_amd; from macjd_amd import hipgraph; "
+            "print(os.environ.get('GPU_MAX_HW_QUEUES'), hipgraph.launch_mode())" % REPO)
+    def run(**env):
+        e = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "MACJD_GRAPH_REPLAY_STREAM")}
+        e.update(env)
+        return subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300).stdout.split()
+    assert run() == ["3", "high"]
+    assert run(GPU_MAX_HW_QUEUES="2") == ["2", "high"]
+    assert run(GPU_MAX_HW_QUEUES="4") == ["4", "current"]
+    assert run(GPU_MAX_HW_QUEUES="4", MACJD_GRAPH_REPLAY_STREAM="high") == ["4", "high"]
+    assert run(MACJD_GRAPH_REPLAY_STREAM="current") == ["3", "current"]
