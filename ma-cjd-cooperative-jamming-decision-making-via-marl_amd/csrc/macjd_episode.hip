@@ -44,7 +44,10 @@ constexpr int EP_H = 64;
 constexpr int EP_LD = EP_H + 8;   // LDS pitch (= 8 mod 16 floats: conflict-free ds_read_b128 fragments)
 constexpr int EP_KQ = EP_H / 16;  // quads of a K = 64 product
 
-template <int J, int A>
+// FLAT (wide scenarios, e.g. 12 jammers): nothing above depends on WHICH agent a row belongs to — the networks are shared
+// and every output is indexed by the flattened row n = env * n_agents + agent — so the workgroup simply owns J = 4 tiles
+// of 16 consecutive rows n (64 rows: 36 KB of LDS instead of 110 KB for 12 agent tiles); same arithmetic per row.
+template <int J, int A, bool FLAT = false>
 __global__ void __launch_bounds__(256) agent_episode_kernel(const macjd_agent_episode_io io) {
     static_assert(J <= 8, "one wave per agent tile in the Q-head phase, two passes above 4");
     __shared__ __attribute__((aligned(16))) float Hl[2][J][16 * EP_LD];   // h_{t-1} / h_t, ping-pong
@@ -56,6 +59,20 @@ __global__ void __launch_bounds__(256) agent_episode_kernel(const macjd_agent_ep
     const int64_t e0 = (int64_t)blockIdx.x * 16;
     const int T = io.T;
     const int64_t E = io.n_envs;
+    const int64_t NA = io.J;                            // agents per env (FLAT: run-time; otherwise == J)
+    const int64_t N = E * NA;                           // rows
+    const int64_t n0 = (int64_t)blockIdx.x * (16 * J);  // FLAT: first row of the workgroup
+    // row of (tile j, row-in-tile r), clamped for the loads; `live`: the row exists
+    auto row_of = [&](int j, int r, bool& live) -> int64_t {
+        if (FLAT) {
+            const int64_t n = n0 + 16 * j + r;
+            live = n < N;
+            return live ? n : N - 1;
+        }
+        const int64_t e = e0 + r;
+        live = e < E;
+        return (live ? e : E - 1) * J + j;
+    };
 
     // ---- episode constants into registers / LDS -------------------------------------------------------------
     // weight fragments (B operands): rows gate * 64 + 16 wave + li of W_hh, row 16 wave + li of W1's h-columns
@@ -79,8 +96,8 @@ __global__ void __launch_bounds__(256) agent_episode_kernel(const macjd_agent_ep
     for (int j = 0; j < J; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int64_t e = e0 + 4 * g + r;
-            const int64_t n = (e < E ? e : E - 1) * J + j;          // clamped: rows past E are computed, never stored
+            bool live;
+            const int64_t n = row_of(j, 4 * g + r, live);           // clamped: rows past the end are computed, never stored
 #pragma unroll
             for (int c = 0; c < 3; ++c) giv[j][r][c] = io.gi[n * io.gi_ld + c * EP_H + u];
             hreg[j][r] = io.h0 ? io.h0[n * EP_H + u] : 0.0f;
@@ -99,9 +116,9 @@ __global__ void __launch_bounds__(256) agent_episode_kernel(const macjd_agent_ep
 #pragma unroll
     for (int pass = 0; pass < (J + 3) / 4; ++pass) {
         const int j = wave + 4 * pass;
-        const int64_t e = e0 + qr;
-        const int64_t ec = e < E ? e : E - 1;
-        const int64_t n = ec * J + (j < J ? j : 0);
+        bool live_q;
+        const int64_t n = row_of(j < J ? j : 0, qr, live_q);
+        const int64_t ec = n / NA, jc = n - ec * NA;      // (env, agent) of the row, for the availability mask
         avail_bits[pass] = 0;
         n_avail[pass] = 0;
 #pragma unroll
@@ -109,7 +126,7 @@ __global__ void __launch_bounds__(256) agent_episode_kernel(const macjd_agent_ep
             pv[pass][a] = io.P_all[n * io.p_ld + a];
             bool av = true;
             if (io.avail) {
-                const int64_t off = ec * io.av_se + (int64_t)(j < J ? j : 0) * io.av_sj + (int64_t)a * io.av_sa;
+                const int64_t off = ec * io.av_se + jc * io.av_sj + (int64_t)a * io.av_sa;
                 av = (io.avail_elem_size == 8) ? (((const int64_t*)io.avail)[off] != 0) : (((const int32_t*)io.avail)[off] != 0);
             }
             avail_bits[pass] |= av ? (1ull << a) : 0ull;
@@ -153,8 +170,9 @@ __global__ void __launch_bounds__(256) agent_episode_kernel(const macjd_agent_ep
                 hreg[j][r] = hnew;
                 const int row = 4 * g + r;
                 Hl[nxt][j][row * EP_LD + u] = hnew;
-                const int64_t e = e0 + row;
-                if (e < E) io.hidden[(((int64_t)t * E + e) * J + j) * EP_H + u] = hnew;   // staging row t: post-update h_t
+                bool live;
+                const int64_t n = row_of(j, row, live);
+                if (live) io.hidden[((int64_t)t * N + n) * EP_H + u] = hnew;   // staging row t: post-update h_t
             }
         __syncthreads();
         // ---- (3) Q-head base = W1[:, :H] h_t + b1 for this wave's 16 units ----
@@ -210,8 +228,9 @@ __global__ void __launch_bounds__(256) agent_episode_kernel(const macjd_agent_ep
                     q[a] += __shfl_xor(q[a], 32, 64);
                     q[a] += b2;
                 }
-                const int64_t e = e0 + qr;
-                if (qq == 0 && e < E) {
+                bool live;
+                const int64_t n = row_of(j, qr, live);
+                if (qq == 0 && live) {
                     // mask, first arg-max, epsilon-greedy (mac.py:142-146, action_selectors.py:34-62): as qhead_select_kernel
                     int best = 0;
                     float bestq = -INFINITY;
@@ -221,7 +240,6 @@ __global__ void __launch_bounds__(256) agent_episode_kernel(const macjd_agent_ep
                         if (qa > bestq) { bestq = qa; best = a; }
                     }
                     int chosen = best;
-                    const int64_t n = e * J + j;
                     if (epsilon > 0.0f) {
                         const uint64_t counter = ctr_base + (uint64_t)(t + 1);
                         const Philox4 rr = philox4x32_10((uint32_t)n, (uint32_t)((uint64_t)n >> 32), (uint32_t)counter,
@@ -241,7 +259,7 @@ __global__ void __launch_bounds__(256) agent_episode_kernel(const macjd_agent_ep
                     float pc = 0.0f;
 #pragma unroll
                     for (int a = 0; a < A; ++a) pc = (a == chosen) ? pv[pass][a] : pc;
-                    const int64_t o = ((int64_t)t * E + e) * J + j;
+                    const int64_t o = (int64_t)t * N + n;
                     io.T_out[o] = chosen;
                     io.P_out[o] = pc;
                 }
@@ -256,8 +274,9 @@ __global__ void __launch_bounds__(256) agent_episode_kernel(const macjd_agent_ep
         for (int j = 0; j < J; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t e = e0 + 4 * g + r;
-                if (e < E) io.h_final[(e * J + j) * EP_H + u] = hreg[j][r];
+                bool live;
+                const int64_t n = row_of(j, 4 * g + r, live);
+                if (live) io.h_final[n * EP_H + u] = hreg[j][r];
             }
     }
 }
@@ -492,7 +511,7 @@ extern "C" int macjd_qhead_taken(const macjd_qtaken_io* io, void* hip_stream) {
 }
 
 extern "C" int macjd_qhead_double_q_supported(int32_t H, int32_t A) {
-    return (H == macjd::EP_H) && (A == 5 || A == 9 || A == 17);
+    return (H == macjd::EP_H) && (A == 5 || A == 9 || A == 17 || A == 33);
 }
 
 extern "C" int macjd_qhead_double_q(const macjd_doubleq_io* io, void* hip_stream) {
@@ -511,14 +530,16 @@ extern "C" int macjd_qhead_double_q(const macjd_doubleq_io* io, void* hip_stream
     hipStream_t s = (hipStream_t)hip_stream;
     if (io->A == 5) hipLaunchKernelGGL((qhead_double_q_kernel<5>), grid, block, 0, s, *io);
     else if (io->A == 9) hipLaunchKernelGGL((qhead_double_q_kernel<9>), grid, block, 0, s, *io);
-    else hipLaunchKernelGGL((qhead_double_q_kernel<17>), grid, block, 0, s, *io);
+    else if (io->A == 17) hipLaunchKernelGGL((qhead_double_q_kernel<17>), grid, block, 0, s, *io);
+    else hipLaunchKernelGGL((qhead_double_q_kernel<33>), grid, block, 0, s, *io);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_qhead_double_q: %s", hipGetErrorString(err));
     return MACJD_OK;
 }
 
 extern "C" int macjd_agent_episode_supported(int32_t J, int32_t H, int32_t A) {
-    return (H == macjd::EP_H) && (J == 2 || J == 3 || J == 6) && (A == 5 || A == 9 || A == 17);
+    // J in {2, 3, 6}: one row tile per agent; any other agent count: four tiles of consecutive rows (FLAT)
+    return (H == macjd::EP_H) && J >= 1 && (A == 5 || A == 9 || A == 17 || A == 33);
 }
 
 extern "C" int macjd_agent_episode(const macjd_agent_episode_io* io, void* hip_stream) {
@@ -535,19 +556,29 @@ extern "C" int macjd_agent_episode(const macjd_agent_episode_io* io, void* hip_s
         return set_err(MACJD_EINVAL, "%s", "macjd_agent_episode: avail_elem_size must be 4 or 8");
     if (((uintptr_t)io->w_hh) & 15) return set_err(MACJD_EINVAL, "%s", "macjd_agent_episode: w_hh must be 16-byte aligned");
     if (io->n_envs == 0) return MACJD_OK;
-    const dim3 grid((unsigned)((io->n_envs + 15) / 16)), block(256);
+    const bool flat = !(io->J == 2 || io->J == 3 || io->J == 6) || io->A == 33;
+    const int64_t wgs = flat ? (io->n_envs * io->J + 63) / 64 : (io->n_envs + 15) / 16;
+    if (wgs > 0x7fffffff) return set_err(MACJD_EINVAL, "%s", "macjd_agent_episode: too many rows for one launch");
+    const dim3 grid((unsigned)wgs), block(256);
     hipStream_t s = (hipStream_t)hip_stream;
 #define MACJD_EP(J_, A_) hipLaunchKernelGGL((agent_episode_kernel<J_, A_>), grid, block, 0, s, *io)
+#define MACJD_EP_FLAT(A_) hipLaunchKernelGGL((agent_episode_kernel<4, A_, true>), grid, block, 0, s, *io)
 #define MACJD_EP_J(J_)                     \
     do {                                   \
         if (io->A == 5) MACJD_EP(J_, 5);   \
         else if (io->A == 9) MACJD_EP(J_, 9); \
         else MACJD_EP(J_, 17);             \
     } while (0)
-    if (io->J == 2) MACJD_EP_J(2);
+    if (flat) {
+        if (io->A == 5) MACJD_EP_FLAT(5);
+        else if (io->A == 9) MACJD_EP_FLAT(9);
+        else if (io->A == 17) MACJD_EP_FLAT(17);
+        else MACJD_EP_FLAT(33);
+    } else if (io->J == 2) MACJD_EP_J(2);
     else if (io->J == 3) MACJD_EP_J(3);
     else MACJD_EP_J(6);
 #undef MACJD_EP_J
+#undef MACJD_EP_FLAT
 #undef MACJD_EP
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_agent_episode: %s", hipGetErrorString(err));

@@ -441,6 +441,421 @@ __global__ void __launch_bounds__(256) mixer_fused_backward_kernel(const macjd_m
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Wide scenarios (J = 12: BASELINE.json's 12 jammers / 16 radars, S = 184).  Same geometry and the same expressions as
+// the kernels above, but the weight fragments of a whole layer no longer fit a lane's registers (first layer: 6 tiles x
+// 12 quads = 288 VGPRs; hyper_w_1's second layer: 12 tiles x 8 quads = 384), so both layers run in PASSES whose
+// fragments are loaded one pass ahead: the first layer two column tiles at a time, the J tiles of w1_raw PJ agents at
+// a time.  The tail's fmaf chain over the agents runs in agent order across the passes, i.e. it is the chain of
+// mixer_tail_kernel / the narrow kernels.
+template <int PJ>
+__device__ __forceinline__ void mx_load_pass(f32x4 (&dst)[PJ][MX_KQ2], const float* __restrict__ W2, int j0, int wave, int li, int g) {
+#pragma unroll
+    for (int jj = 0; jj < PJ; ++jj) mx_load_frags<MX_KQ2, false>(dst[jj], W2, MX_HH, (j0 + jj) * MX_EM + 16 * wave + li, g);
+}
+
+template <int PJ>
+__device__ __forceinline__ void mx_pass_tiles(const float* __restrict__ Hs, const f32x4 (&B2)[PJ][MX_KQ2], f32x4 (&acc2)[PJ],
+                                              int li, int g) {
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) acc2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* a1p = Hs + li * MX_LDH + 4 * g;            // h_w1: columns [0, Hh)
+#pragma unroll
+    for (int Q = 0; Q < MX_KQ2; ++Q) {
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(a1p + 16 * Q);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int j = 0; j < PJ; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[jj], B2[j][Q][jj], acc2[j], 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void mx_wf_tile(const float* __restrict__ Hs, const f32x4 (&Bf)[MX_KQ2], f32x4& accf, int li, int g) {
+    accf = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* afp = Hs + li * MX_LDH + 4 * g + MX_HH;    // h_wf: columns [Hh, 2 Hh)
+#pragma unroll
+    for (int Q = 0; Q < MX_KQ2; ++Q) {
+        const f32x4 af = *reinterpret_cast<const f32x4*>(afp + 16 * Q);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) accf = __builtin_amdgcn_mfma_f32_16x16x4f32(af[jj], Bf[Q][jj], accf, 0, 0, 0);
+    }
+}
+
+template <int J, int SQ, bool SAVE, int PJ>
+__global__ void __launch_bounds__(256) mixer_fused_forward_wide_kernel(const macjd_mixerf_io io) {
+    static_assert(J % PJ == 0, "whole passes");
+    constexpr int LDA = 16 * SQ + 8;
+    constexpr int T1W = MX_N1 / 16 / 4;   // 6 first-layer column tiles per wave
+    constexpr int P1W = 2;                // ... two per pass
+    constexpr int NP = J / PJ;
+    __shared__ __attribute__((aligned(16))) float As[16 * LDA];
+    __shared__ __attribute__((aligned(16))) float Hs[16 * MX_LDH];
+    __shared__ float part[4][16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    const int64_t m0 = (int64_t)blockIdx.x * 16;
+    const int S = io.S;
+
+    float x[SQ], lnw[SQ], lnb[SQ];
+    {
+        const int64_t m = m0 + 4 * wave + g;
+#pragma unroll
+        for (int c = 0; c < SQ; ++c) {
+            const int col = li + 16 * c, cc = col < S ? col : S - 1;
+            x[c] = io.s[(m < io.M ? m : io.M - 1) * io.s_ld + cc];
+            lnw[c] = io.ln_w[cc];
+            lnb[c] = io.ln_b[cc];
+        }
+    }
+    float b1v[T1W], b2e[J], wv[16];
+#pragma unroll
+    for (int i = 0; i < T1W; ++i) b1v[i] = io.b1[16 * (T1W * wave + i) + li];
+#pragma unroll
+    for (int j = 0; j < J; ++j) b2e[j] = io.b2[j * MX_EM + 16 * wave + li];
+    const float bfe = io.bf2[16 * wave + li];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wv[k] = io.wV2[16 * g + k];
+    const float bV2 = io.bV2[0];
+    // first-layer fragments of passes 0 and 1 (the third pass re-uses the first buffer)
+    f32x4 B1a[P1W][SQ], B1b[P1W][SQ];
+#pragma unroll
+    for (int i = 0; i < P1W; ++i) mx_load_frags<SQ, true>(B1a[i], io.W1, S, 16 * (T1W * wave + i) + li, g);
+#pragma unroll
+    for (int i = 0; i < P1W; ++i) mx_load_frags<SQ, true>(B1b[i], io.W1, S, 16 * (T1W * wave + P1W + i) + li, g);
+    float qv[4][J];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t m = m0 + 4 * g + r;
+        const int64_t mc = m < io.M ? m : io.M - 1;
+#pragma unroll
+        for (int j = 0; j < J; ++j) qv[r][j] = io.q[mc * J + j];
+    }
+
+    // ---- phase 0: LayerNorm ----
+    {
+        const int row = 4 * wave + g;
+        const int64_t m = m0 + row;
+        float sum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < SQ; ++c) {
+            x[c] = (li + 16 * c < S) ? x[c] : 0.0f;
+            sum += x[c];
+        }
+        const float mean = mx_sum16(sum) / (float)S;
+        float sq = 0.0f;
+#pragma unroll
+        for (int c = 0; c < SQ; ++c) {
+            const float d = (li + 16 * c < S) ? x[c] - mean : 0.0f;
+            sq = fmaf(d, d, sq);
+        }
+        const float rstd = rsqrtf(mx_sum16(sq) / (float)S + io.ln_eps);
+#pragma unroll
+        for (int c = 0; c < SQ; ++c) {
+            const int col = li + 16 * c;
+            const bool live = col < S;
+            const float xh = live ? (x[c] - mean) * rstd : 0.0f;
+            const float v = live ? xh * lnw[c] + lnb[c] : 0.0f;
+            As[row * LDA + col] = v;
+            if (SAVE && live && m < io.M) {
+                io.sn[m * S + col] = v;
+                io.xhat[m * S + col] = xh;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1: merged first layer, this wave's 6 column tiles in three passes of two ----
+    auto first_layer_pass = [&](const f32x4 (&B1)[P1W][SQ], int pass) {
+        f32x4 acc[P1W];
+#pragma unroll
+        for (int i = 0; i < P1W; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* ap = As + li * LDA + 4 * g;
+#pragma unroll
+        for (int Q = 0; Q < SQ; ++Q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ap + 16 * Q);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int i = 0; i < P1W; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], B1[i][Q][jj], acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < P1W; ++i) {
+            const int t = P1W * pass + i;
+            const int col = 16 * (T1W * wave + t) + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * g + r;
+                float v = acc[i][r] + b1v[t];
+                v = (col < MX_RELU) ? fmaxf(v, 0.0f) : v;
+                Hs[row * MX_LDH + col] = v;
+                if (SAVE && m0 + row < io.M) io.act[(m0 + row) * MX_N1 + col] = v;
+            }
+        }
+    };
+    first_layer_pass(B1a, 0);
+#pragma unroll
+    for (int i = 0; i < P1W; ++i) mx_load_frags<SQ, true>(B1a[i], io.W1, S, 16 * (T1W * wave + 2 * P1W + i) + li, g);
+    // second-layer fragments of the first agent pass and of w_final: in flight under the rest of phase 1
+    f32x4 B2a[PJ][MX_KQ2], B2b[PJ][MX_KQ2], Bf[MX_KQ2];
+    mx_load_pass<PJ>(B2a, io.W2, 0, wave, li, g);
+    mx_load_frags<MX_KQ2, false>(Bf, io.Wf2, MX_HH, 16 * wave + li, g);
+    first_layer_pass(B1b, 1);
+    first_layer_pass(B1a, 2);
+    __syncthreads();
+
+    // ---- phase 2: second layers for embed block `wave` in NP agent passes, tail ----
+    const int e = 16 * wave + li;
+    float hid[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hid[r] = mx_clamp(Hs[(4 * g + r) * MX_LDH + MX_RELU + e], -5.0f, 5.0f);
+    f32x4 accf;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        f32x4 acc2[PJ];
+        if (p + 1 < NP) {
+            if (p & 1) mx_load_pass<PJ>(B2a, io.W2, (p + 1) * PJ, wave, li, g);
+            else mx_load_pass<PJ>(B2b, io.W2, (p + 1) * PJ, wave, li, g);
+        }
+        if (p & 1) mx_pass_tiles<PJ>(Hs, B2b, acc2, li, g);
+        else mx_pass_tiles<PJ>(Hs, B2a, acc2, li, g);
+        if (p == 0) mx_wf_tile(Hs, Bf, accf, li, g);
+#pragma unroll
+        for (int jj = 0; jj < PJ; ++jj) {
+            const int j = p * PJ + jj;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hid[r] = fmaf(qv[r][j], mx_clamp(acc2[jj][r] + b2e[j], 0.0f, 5.0f), hid[r]);   // bmm(q, w1) + b1
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r;
+        const float h = hid[r] > 0.0f ? hid[r] : expm1f(hid[r]);                                   // F.elu
+        const float t = mx_sum16(h * mx_clamp(accf[r] + bfe, 0.0f, 5.0f));                         // bmm(hidden, w_final)
+        if (li == 0) part[wave][row] = t;
+    }
+    const float v_raw = (wave == 0) ? mx_v_raw(Hs, wv, bV2, li, g) : 0.0f;
+    __syncthreads();
+    if (wave == 0 && g == 0) {
+        const int64_t m = m0 + li;
+        if (m < io.M) io.y[m] = ((part[0][li] + part[1][li]) + (part[2][li] + part[3][li])) + mx_clamp(v_raw, -5.0f, 5.0f);
+    }
+}
+
+template <int J, int PJ, bool TD = false>
+__global__ void __launch_bounds__(256) mixer_fused_backward_wide_kernel(const macjd_mixerf_io io, const macjd_tdloss_io td,
+                                                                         const float* __restrict__ tot_m) {
+    static_assert(J % PJ == 0, "whole passes");
+    constexpr int NP = J / PJ;
+    constexpr int LDG = PJ * MX_EM + 8;     // pitch of ONE pass of g_w1raw in LDS (= 8 mod 16)
+    constexpr int LDF = MX_EM + 8;
+    constexpr int KQP = PJ * MX_EM / 16;    // quads of one pass of the transposed hyper_w_1.2 product
+    constexpr int KQF = MX_EM / 16;
+    __shared__ __attribute__((aligned(16))) float Hs[16 * MX_LDH];
+    __shared__ __attribute__((aligned(16))) float G1[16 * LDG];
+    __shared__ __attribute__((aligned(16))) float Gf[16 * LDF];
+    __shared__ float gq_part[4][16][J];
+    __shared__ float gv_s[16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    const int64_t m0 = (int64_t)blockIdx.x * 16;
+
+    f32x4 B2a[PJ][MX_KQ2], B2b[PJ][MX_KQ2], Bf[MX_KQ2];
+    mx_load_pass<PJ>(B2a, io.W2, 0, wave, li, g);
+    mx_load_frags<MX_KQ2, false>(Bf, io.Wf2, MX_HH, 16 * wave + li, g);
+    float b2e[J], wv[16], wvo[4];
+#pragma unroll
+    for (int j = 0; j < J; ++j) b2e[j] = io.b2[j * MX_EM + 16 * wave + li];
+    const float bfe = io.bf2[16 * wave + li];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wv[k] = io.wV2[16 * g + k];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wvo[i] = io.wV2[(threadIdx.x + 256 * i) & (MX_EM - 1)];
+    const float bV2 = io.bV2[0];
+    auto load_gy = [&](const int64_t mc) -> float {
+        if constexpr (TD) {
+            const int cols = (int)td.gy_cols;
+            const int b = (int)(mc / cols), t = (int)(mc - (int64_t)b * cols);
+            const int tc = t < td.Tm1 ? t : td.Tm1 - 1;
+            const float term = td.terminated[b * td.t_sb + tc * td.t_st] ? 1.0f : 0.0f;
+            const float mk = td.filled[b * td.f_sb + tc * td.f_st] ? 1.0f : 0.0f;
+            const float target = td.reward[b * td.r_sb + tc * td.r_st] + td.gamma * (1.0f - term) * td.tq[b * td.tq_sb + tc];
+            const float scale = 2.0f / tot_m[0];
+            const float gv = scale * mk * (td.y[b * td.y_sb + tc] - target);
+            return t < td.Tm1 ? gv : 0.0f;
+        } else {
+            return io.gy[mc];
+        }
+    };
+    const float gy_li = load_gy((m0 + li < io.M) ? m0 + li : io.M - 1);
+    float qv[4][J], gyv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t m = m0 + 4 * g + r;
+        const int64_t mc = m < io.M ? m : io.M - 1;
+        gyv[r] = load_gy(mc);
+#pragma unroll
+        for (int j = 0; j < J; ++j) qv[r][j] = io.q[mc * J + j];
+    }
+    for (int idx = threadIdx.x; idx < 16 * (MX_N1 / 4); idx += 256) {
+        const int row = idx / (MX_N1 / 4), c4 = idx - row * (MX_N1 / 4);
+        const int64_t mc = (m0 + row < io.M) ? m0 + row : io.M - 1;
+        *reinterpret_cast<f32x4*>(Hs + row * MX_LDH + 4 * c4) = *reinterpret_cast<const f32x4*>(io.act + mc * MX_N1 + 4 * c4);
+    }
+    __syncthreads();
+
+    // ---- sweep 1: recompute the w1_raw tiles of embed block `wave` pass by pass (kept: 4 J values per lane), hid ----
+    const int e = 16 * wave + li;
+    float w1r[J][4], hid[4], b1r[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        b1r[r] = Hs[(4 * g + r) * MX_LDH + MX_RELU + e];
+        hid[r] = mx_clamp(b1r[r], -5.0f, 5.0f);
+    }
+    f32x4 accf;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        f32x4 acc2[PJ];
+        if (p + 1 < NP) {
+            if (p & 1) mx_load_pass<PJ>(B2a, io.W2, (p + 1) * PJ, wave, li, g);
+            else mx_load_pass<PJ>(B2b, io.W2, (p + 1) * PJ, wave, li, g);
+        }
+        if (p & 1) mx_pass_tiles<PJ>(Hs, B2b, acc2, li, g);
+        else mx_pass_tiles<PJ>(Hs, B2a, acc2, li, g);
+        if (p == 0) mx_wf_tile(Hs, Bf, accf, li, g);
+#pragma unroll
+        for (int jj = 0; jj < PJ; ++jj) {
+            const int j = p * PJ + jj;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                w1r[j][r] = acc2[jj][r] + b2e[j];
+                hid[r] = fmaf(qv[r][j], mx_clamp(w1r[j][r], 0.0f, 5.0f), hid[r]);
+            }
+        }
+    }
+    const float v_raw = (wave == 0) ? mx_v_raw(Hs, wv, bV2, li, g) : 0.0f;
+    float ghid[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r;
+        const int64_t m = m0 + row;
+        const float h = hid[r] > 0.0f ? hid[r] : expm1f(hid[r]);
+        const float wfr = accf[r] + bfe;
+        ghid[r] = gyv[r] * mx_clamp(wfr, 0.0f, 5.0f) * (hid[r] > 0.0f ? 1.0f : h + 1.0f);
+        const float gwf = (wfr >= 0.0f && wfr <= 5.0f) ? gyv[r] * h : 0.0f;
+        const float gb1 = (b1r[r] >= -5.0f && b1r[r] <= 5.0f) ? ghid[r] : 0.0f;
+        Gf[row * LDF + e] = gwf;
+        if (m < io.M) {
+            io.g_wfraw[m * MX_EM + e] = gwf;
+            io.gout1[m * MX_N1 + MX_RELU + e] = gb1;
+        }
+    }
+    if (wave == 0 && g == 0) {
+        const int64_t m = m0 + li;
+        const float gv = (v_raw >= -5.0f && v_raw <= 5.0f) ? gy_li : 0.0f;
+        gv_s[li] = gv;
+        if (m < io.M) io.g_v[m] = gv;
+    }
+
+    // ---- sweep 2: per agent pass, the tile gradients -> LDS / HBM, then that pass's share of the transposed product ----
+    f32x4 a1[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) a1[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int p = 0; p < NP; ++p) {
+        // this pass's transposed fragments: rows k = p PJ Em + 16 Q + 4 g + jj of W2, column n = 16 (2 wave + tt) + li
+        f32x4 D1[2][KQP];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int n = 16 * (2 * wave + tt) + li;
+#pragma unroll
+            for (int Q = 0; Q < KQP; ++Q)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) D1[tt][Q][jj] = io.W2[(int64_t)(p * PJ * MX_EM + 16 * Q + 4 * g + jj) * MX_HH + n];
+        }
+        if (p > 0) __syncthreads();          // the previous pass's readers of G1 are done
+#pragma unroll
+        for (int jj = 0; jj < PJ; ++jj) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * g + r;
+                const int64_t m = m0 + row;
+                // (w1r is indexed with the run-time pass: selected through a compile-time scan so that it stays in registers)
+                float w = 0.0f, qj = 0.0f;
+#pragma unroll
+                for (int pp = 0; pp < NP; ++pp) {
+                    w = (pp == p) ? w1r[pp * PJ + jj][r] : w;
+                    qj = (pp == p) ? qv[r][pp * PJ + jj] : qj;
+                }
+                const int j = p * PJ + jj;
+                const float gw = (w >= 0.0f && w <= 5.0f) ? ghid[r] * qj : 0.0f;
+                G1[row * LDG + jj * MX_EM + e] = gw;
+                if (m < io.M) io.g_w1raw[m * (J * MX_EM) + j * MX_EM + e] = gw;
+                const float t = mx_sum16(ghid[r] * mx_clamp(w, 0.0f, 5.0f));
+                if (li == 0) gq_part[wave][row][j] = t;
+            }
+        }
+        __syncthreads();
+        const float* gp = G1 + li * LDG + 4 * g;
+#pragma unroll
+        for (int Q = 0; Q < KQP; ++Q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(gp + 16 * Q);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) a1[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], D1[tt][Q][jj], a1[tt], 0, 0, 0);
+        }
+    }
+    // dL/dq: the four embed blocks' partial sums in fixed order (gq_part complete: barrier inside the last pass)
+    for (int idx = threadIdx.x; idx < 16 * J; idx += 256) {
+        const int row = idx / J, j = idx - row * J;
+        if (m0 + row < io.M)
+            io.gq[(m0 + row) * J + j] = (gq_part[0][row][j] + gq_part[1][row][j]) + (gq_part[2][row][j] + gq_part[3][row][j]);
+    }
+    {
+        f32x4 Df[2][KQF], af[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int n = 16 * (2 * wave + tt) + li;
+            af[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int Q = 0; Q < KQF; ++Q)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) Df[tt][Q][jj] = io.Wf2[(int64_t)(16 * Q + 4 * g + jj) * MX_HH + n];
+        }
+        const float* fp = Gf + li * LDF + 4 * g;
+#pragma unroll
+        for (int Q = 0; Q < KQF; ++Q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(fp + 16 * Q);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) af[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], Df[tt][Q][jj], af[tt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int n = 16 * (2 * wave + tt) + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * g + r;
+                const int64_t m = m0 + row;
+                if (m < io.M) {
+                    io.gout1[m * MX_N1 + n] = (Hs[row * MX_LDH + n] > 0.0f) ? a1[tt][r] : 0.0f;
+                    io.gout1[m * MX_N1 + MX_HH + n] = (Hs[row * MX_LDH + MX_HH + n] > 0.0f) ? af[tt][r] : 0.0f;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16 * MX_EM / 256; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        const int row = idx / MX_EM, k = idx - row * MX_EM;
+        if (m0 + row < io.M)
+            io.gout1[(m0 + row) * MX_N1 + 2 * MX_HH + k] = (Hs[row * MX_LDH + 2 * MX_HH + k] > 0.0f) ? gv_s[row] * wvo[i] : 0.0f;
+    }
+}
+
 static int mixerf_check(const macjd_mixerf_io* io, bool backward, bool gy_from_td = false) {
     if (!io) return set_err(MACJD_EINVAL, "%s", "macjd_mixer_fused: NULL io");
     if (!macjd_mixer_fused_supported(io->J, io->S, io->Hh, io->Em))
@@ -464,7 +879,7 @@ static int mixerf_check(const macjd_mixerf_io* io, bool backward, bool gy_from_t
 
 extern "C" int macjd_mixer_fused_supported(int32_t J, int32_t S, int32_t Hh, int32_t Em) {
     if (Hh != macjd::MX_HH || Em != macjd::MX_EM || S < 1) return 0;
-    return (J == 2 && S <= 32) || (J == 3 && S <= 48) || (J == 6 && S <= 96);
+    return (J == 2 && S <= 32) || (J == 3 && S <= 48) || (J == 6 && S <= 96) || (J == 12 && S <= 192);
 }
 
 extern "C" int macjd_mixer_fused_forward(const macjd_mixerf_io* io, void* hip_stream) {
@@ -481,7 +896,9 @@ extern "C" int macjd_mixer_fused_forward(const macjd_mixerf_io* io, void* hip_st
     } while (0)
     if (io->J == 2) MACJD_MXF(2, 2);
     else if (io->J == 3) MACJD_MXF(3, 3);
-    else MACJD_MXF(6, 6);
+    else if (io->J == 6) MACJD_MXF(6, 6);
+    else if (io->save) hipLaunchKernelGGL((mixer_fused_forward_wide_kernel<12, 12, true, 4>), grid, block, 0, s, *io);
+    else hipLaunchKernelGGL((mixer_fused_forward_wide_kernel<12, 12, false, 4>), grid, block, 0, s, *io);
 #undef MACJD_MXF
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_mixer_fused_forward: %s", hipGetErrorString(err));
@@ -498,7 +915,8 @@ extern "C" int macjd_mixer_fused_backward(const macjd_mixerf_io* io, void* hip_s
     const macjd_tdloss_io none{};
     if (io->J == 2) hipLaunchKernelGGL((mixer_fused_backward_kernel<2>), grid, block, 0, s, *io, none, nullptr);
     else if (io->J == 3) hipLaunchKernelGGL((mixer_fused_backward_kernel<3>), grid, block, 0, s, *io, none, nullptr);
-    else hipLaunchKernelGGL((mixer_fused_backward_kernel<6>), grid, block, 0, s, *io, none, nullptr);
+    else if (io->J == 6) hipLaunchKernelGGL((mixer_fused_backward_kernel<6>), grid, block, 0, s, *io, none, nullptr);
+    else hipLaunchKernelGGL((mixer_fused_backward_wide_kernel<12, 4>), grid, block, 0, s, *io, none, nullptr);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_mixer_fused_backward: %s", hipGetErrorString(err));
     return MACJD_OK;
@@ -518,7 +936,8 @@ extern "C" int macjd_mixer_fused_backward_td(const macjd_mixerf_io* io, const ma
     hipStream_t s = (hipStream_t)hip_stream;
     if (io->J == 2) hipLaunchKernelGGL((mixer_fused_backward_kernel<2, true>), grid, block, 0, s, *io, *td, tot_m);
     else if (io->J == 3) hipLaunchKernelGGL((mixer_fused_backward_kernel<3, true>), grid, block, 0, s, *io, *td, tot_m);
-    else hipLaunchKernelGGL((mixer_fused_backward_kernel<6, true>), grid, block, 0, s, *io, *td, tot_m);
+    else if (io->J == 6) hipLaunchKernelGGL((mixer_fused_backward_kernel<6, true>), grid, block, 0, s, *io, *td, tot_m);
+    else hipLaunchKernelGGL((mixer_fused_backward_wide_kernel<12, 4, true>), grid, block, 0, s, *io, *td, tot_m);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_mixer_fused_backward_td: %s", hipGetErrorString(err));
     return MACJD_OK;

@@ -107,13 +107,25 @@ __global__ void __launch_bounds__(HS > 4 ? 64 * HS : 256) qhead_select_kernel(co
         }
         __syncthreads();
         if (wave > 0 || !row_live) return;
+        if constexpr (AMAX > 17) {
+            // wide action sets: one wave's partial sums at a time (fully unrolled, the (HS - 1) x A loads are all hoisted
+            // to the top and hold (HS - 1) x A registers: 231 at A = 33 — scratch spills)
+#pragma unroll 1
+            for (int w = 0; w < HS - 1; ++w)
 #pragma unroll
-        for (int w = 0; w < HS - 1; ++w)
+                for (int a = 0; a < AMAX; ++a) {
+                    if (!AT && a >= A) break;
+                    acc[a] += s_part[(w * AMAX + a) * 64 + lane];
+                }
+        } else {
 #pragma unroll
-            for (int a = 0; a < AMAX; ++a) {
-                if (!AT && a >= A) break;
-                acc[a] += s_part[(w * AMAX + a) * 64 + lane];
-            }
+            for (int w = 0; w < HS - 1; ++w)
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a) {
+                    if (!AT && a >= A) break;
+                    acc[a] += s_part[(w * AMAX + a) * 64 + lane];
+                }
+        }
     }
     const float b2 = io.b2[0];
 #pragma unroll

@@ -68,7 +68,9 @@ def gen_nets(out_dir, ref_root):
         import yaml
 
         quiet = contextlib.redirect_stdout(io.StringIO())
-        for tag, (J, R, H) in {"3j4r_h64": (3, 4, 64), "2j2r_h128": (2, 2, 128), "6j8r_h64": (6, 8, 64)}.items():
+        # (J, R, H, learner steps recorded): the wide configs carry fewer G5 steps (fixture size)
+        tags = {"3j4r_h64": (3, 4, 64, 3), "2j2r_h128": (2, 2, 128, 3), "6j8r_h64": (6, 8, 64, 0), "12j16r_h64": (12, 16, 64, 1)}
+        for tag, (J, R, H, n_g5) in tags.items():
             args = _args(J, R, H)
             A, S = args.n_actions, args.state_shape
             rec = {"dims_json": json.dumps(dict(J=J, R=R, H=H, A=A, S=S))}
@@ -131,7 +133,7 @@ def gen_nets(out_dir, ref_root):
                 qtot_big = big(torch.tensor(qv).view(4, 10, J), torch.tensor(st).view(4, 10, S))
             rec.update(g4_q=qv, g4_s=st, g4_qtot=qtot.numpy(), g4_qtot_big=qtot_big.numpy())
             # ---------------- G5: learner steps ----------------
-            if tag == "6j8r_h64":  # agent / mixer vectors only for the wide config (fixture size)
+            if n_g5 == 0:  # agent / mixer vectors only
                 np.savez_compressed(os.path.join(out_dir, f"nets_{tag}.npz"), **rec)
                 print(f"nets_{tag}.npz")
                 continue
@@ -143,7 +145,7 @@ def gen_nets(out_dir, ref_root):
             rec.update(_sd("g5_mixer0.", learner.eval_qmix_net.state_dict()))
             B, T = 4, 12
             stats_all = []
-            for step, lengths in enumerate(([T] * B, [T, 7, 12, 3], [5, 5, 5, 5])):
+            for step, lengths in enumerate(([T] * B, [T, 7, 12, 3], [5, 5, 5, 5])[:n_g5]):
                 batch = _synthetic_batch(np.random.default_rng(100 + step), args, B, T, lengths)
                 if step == 2:  # buffer.sample truncates to the longest episode in the batch
                     L = 5
@@ -251,14 +253,23 @@ def gen_nets(out_dir, ref_root):
         # No torch RNG is consumed in test mode (action_selectors.py:58-60), so a MAC on a HIP device — whose exploration
         # draws come from the fused kernel's own Philox stream — must reproduce these episodes exactly as well.
         args = _args(3, 4, 64, episode_limit=100, buffer_size=4)
-        np.random.seed(7); torch.manual_seed(1234)
+        np.random.seed(7); torch.manual_seed(6)
         with quiet:
             env = ElectromagneticEnvironment(args, path)
             args.env_info = env.get_env_info()
             mac = BasicMAC(args.obs_shape, args)
-            with torch.no_grad():   # default init gives near-constant Q over time; spread the Q-head so greedy actions vary
+            with torch.no_grad():
+                # The observation is constant, so the greedy action changes only through the hidden state.  With the default
+                # initialisation fc1's output saturates the GRU gates on the raw observation (powers of 300 W, ranges of
+                # 400 m): h is constant after one step and so is the action.  Weights re-scaled so that the recurrence has
+                # its own dynamics and the Q-head looks at it: fc1 x 0.003, W_hh x 6, the Q-head's h-columns x 16, the
+                # whole Q-head x 2 -> 7 distinct greedy actions, 31 changes per episode, smallest top-2 Q gap 1.1e-3;
+                # float32 / float64 / float32 + 1e-5 noise on h give the same action sequence (checked when chosen).
                 for p_ in mac.agent.fc2_q_head.parameters():
-                    p_.mul_(4.0)
+                    p_.mul_(2.0)
+                mac.agent.fc2_q_head[0].weight[:, :args.rnn_hidden_dim].mul_(16.0)
+                mac.agent.rnn.weight_hh.mul_(6.0)
+                mac.agent.fc1.weight.mul_(0.003)
             buf = EpisodeReplayBuffer(args)
             runner = EpisodeRunner(env, mac, buf, args)
         rec = {"scenario_json": json.dumps(sc), "args_json": json.dumps({k: v for k, v in vars(args).items()

@@ -30,7 +30,7 @@ def _gpu_args(d, **kw):
     return make_args(d, device="cuda", use_cuda=True, **kw)
 
 
-@pytest.mark.parametrize("tag", ["3j4r_h64", "2j2r_h128", "6j8r_h64"])
+@pytest.mark.parametrize("tag", ["3j4r_h64", "2j2r_h128", "6j8r_h64", "12j16r_h64"])
 @pytest.mark.parametrize("N_envs", [5, 4096])
 def test_fused_qhead_vs_oracle(tag, N_envs):
     """All-action Q (one launch) == the reference's per-action loop (oracle), incl. at rollout size."""
@@ -89,7 +89,7 @@ def test_double_q_helper_equals_argmax_gather():
     assert torch.equal(got, want)
 
 
-@pytest.mark.parametrize("tag", ["3j4r_h64", "6j8r_h64"])
+@pytest.mark.parametrize("tag", ["3j4r_h64", "6j8r_h64", "12j16r_h64"])
 @pytest.mark.parametrize("N", [9696, 37])
 def test_double_q_from_hidden_states_kernel(tag, N):
     """One launch from the hidden states (base products on MFMA, both all-action Q-heads, arg-max, gather) == the
@@ -176,7 +176,7 @@ def test_fused_selection_exploration_statistics():
     assert torch.equal(t3, run(0.3, 2)) and not torch.equal(t3, run(0.3, 3))
 
 
-@pytest.mark.parametrize("tag", ["3j4r_h64", "2j2r_h128", "6j8r_h64"])
+@pytest.mark.parametrize("tag", ["3j4r_h64", "2j2r_h128", "6j8r_h64", "12j16r_h64"])
 def test_mac_on_gpu_matches_reference(tag):
     """BasicMAC.select_actions(test_mode=True) on the HIP path vs the reference's outputs (G3)."""
     from macjd_amd.core.mac import BasicMAC
@@ -196,7 +196,7 @@ def test_mac_on_gpu_matches_reference(tag):
         assert mac.last_actions_T32.dtype == torch.int32 and mac.last_actions_T32.stride() == (1, 5)
 
 
-@pytest.mark.parametrize("tag", ["3j4r_h64", "2j2r_h128"])
+@pytest.mark.parametrize("tag", ["3j4r_h64", "2j2r_h128", "12j16r_h64"])
 def test_learner_on_gpu_matches_reference(tag):
     """G5 on the device: stats within 1e-5 (relative to their scale), gradients, None-grad set."""
     from macjd_amd.core.mac import BasicMAC
@@ -210,7 +210,7 @@ def test_learner_on_gpu_matches_reference(tag):
     learner.eval_qmix_net.load_state_dict(sd_from(g, "g5_mixer0."))
     learner._update_targets()
     assert next(mac.agent.parameters()).is_cuda
-    for step in range(3):
+    for step in range(len(g["g5_stats"])):      # (12j/16r carries one step)
         pre = f"g5_b{step}_"
         batch = {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)}
         batch["max_seq_len"] = int(batch["max_seq_len"])
@@ -393,6 +393,66 @@ def test_reference_greedy_episodes_with_mac_on_gpu():
     assert buf.current_size == int(g["buffer_size_after"]) == 0 and runner.t_env == int(g["t_env_after"])
 
 
+def test_fused_rollout_kernel_reproduces_reference_greedy_episodes():
+    """The launches bench.py times, pinned on a reference output: two greedy episodes of the REFERENCE's own runner
+    (tests/golden/episode_greedy.npz: 7 distinct greedy actions, 31 changes per episode) replayed by
+    BatchedEpisodeRunner.rollout_fused(test_mode=True) — ops.agent_episode (GRU cell + all-action Q-head + arg-max for
+    all 100 steps in one launch) + env.step_many — on E = 16 replicas of the one env.  The observation is static, so the
+    greedy action sequence depends on the agent alone: actions bit-exact in every replica, chosen powers within 1e-5; the
+    deterministic reward term (avg_r_p), the mean power and the action distribution equal the reference's run_info; the
+    Monte-Carlo terms are compared with the step-by-step env.step() on the same actions (same Philox streams: bitwise)."""
+    from macjd_amd.core.mac import BasicMAC
+    from macjd_amd.runners.episode_runner import BatchedEpisodeRunner
+    from macjd_amd.scenario import Scenario
+    from macjd_amd.simulation.environment import BatchedElectromagneticEnvironment
+    from macjd_amd.utils.replay_buffer import EpisodeReplayBuffer
+    g = np.load(os.path.join(GOLDEN, "episode_greedy.npz"))
+    a = json.loads(str(g["args_json"]))
+    a.update(device="cuda", use_cuda=True)
+    args = SimpleNamespace(**a)
+    sc = Scenario.from_dict(json.loads(str(g["scenario_json"])))
+    E, T, J = 16, args.episode_limit, args.n_agents
+    assert len(np.unique(g["step_T"])) >= 5, "the fixture must exercise the arg-max"
+
+    def build():
+        env = BatchedElectromagneticEnvironment(scenario=sc, batch_envs=E, device=DEV, seed=3)
+        args.env_info = env.get_env_info()
+        with quiet():
+            mac = BasicMAC(args.obs_shape, args)
+            mac.load_state(sd_from(g, "agent."))
+            mac.cuda()
+            buf = EpisodeReplayBuffer(args, device="cuda")
+        return env, mac, BatchedEpisodeRunner(env, mac, buf, args)
+
+    env, mac, runner = build()
+    assert runner.fused_rollout_available()
+    env2, _, _ = build()                      # step-by-step twin of the environment (same seed: same Philox streams)
+    env2.reset()
+    for ep in range(2):
+        ri = runner.run(test_mode=True, store=False, sync_stats=True)
+        st = runner.stage
+        got_T = st["actions_discrete"][:T, :, :, 0].cpu().numpy()               # [T, E, J]
+        got_P = st["actions_continuous"][:T, :, :, 0].cpu().numpy()
+        ref_T, ref_P = g["step_T"][ep * T:(ep + 1) * T], g["step_P"][ep * T:(ep + 1) * T]     # [T, J]
+        for e in range(E):
+            np.testing.assert_array_equal(got_T[:, e], ref_T, err_msg=f"episode {ep}, replica {e}")
+        np.testing.assert_allclose(got_P, np.broadcast_to(ref_P[:, None, :], got_P.shape), atol=TOL, rtol=0)
+        for k in ("avg_r_p", "avg_power_overall"):
+            assert ri[k] == pytest.approx(float(g[f"ep{ep}_{k}"]), rel=1e-6, abs=1e-5), (ep, k)
+        np.testing.assert_allclose(ri["action_distribution"], g[f"ep{ep}_action_distribution"], atol=1e-6)
+        # the env half of the fused rollout against single-step launches on the reference's actions
+        if ep > 0:
+            env2.reset()
+        for t in range(T):
+            rew, term, _ = env2.step(torch.from_numpy(np.broadcast_to(ref_T[t].astype(np.int32), (E, J)).copy()).to(DEV),
+                                     torch.from_numpy(np.broadcast_to(ref_P[t].astype(np.float32), (E, J)).copy()).to(DEV))
+            if np.array_equal(got_P[t], np.broadcast_to(ref_P[t].astype(np.float32), (E, J))):   # (bitwise-equal powers)
+                assert torch.equal(st["reward"][t].view(E), rew), (ep, t)
+            else:
+                np.testing.assert_allclose(st["reward"][t].view(E).cpu().numpy(), rew.cpu().numpy(), atol=TOL, rtol=0)
+            assert torch.equal(st["terminated"][t].view(E), term)
+
+
 def test_replay_buffer_on_gpu_against_reference():
     """G7 with the buffer in HBM: 6 episodes (lengths 6,2,6,4,1,6) into a 4-slot ring — stored arrays incl. padding /
     filled / terminated, ring cursor, np.random-driven sampling (indices, max_seq_len, truncation) — and the learner's
@@ -435,7 +495,7 @@ def test_replay_buffer_on_gpu_against_reference():
         assert not o[:, v.shape[1]:].any(), k
 
 
-@pytest.mark.parametrize("tag", ["3j4r_h64", "2j2r_h128", "6j8r_h64"])
+@pytest.mark.parametrize("tag", ["3j4r_h64", "2j2r_h128", "6j8r_h64", "12j16r_h64"])
 @pytest.mark.parametrize("M", [3232, 37])
 def test_fused_mixer_chain_vs_reference_and_unfused_path(tag, M, monkeypatch):
     """The whole mixer as one MFMA launch per direction (csrc/macjd_mixer.hip): Q_tot against the reference's G4 values
@@ -448,7 +508,7 @@ def test_fused_mixer_chain_vs_reference_and_unfused_path(tag, M, monkeypatch):
     mixer = QMixer(_gpu_args(d)).to(DEV)
     sd = sd_from(g, "mixer.")
     mixer.load_state_dict(sd)
-    assert mixer.fused_available(torch.zeros(1, device=DEV))
+    assert mixer.fused_available(torch.zeros(1, device=DEV)), "every BASELINE.json size has the one-launch mixer"
     q4, s4 = torch.tensor(g["g4_q"]).to(DEV), torch.tensor(g["g4_s"]).to(DEV)
     with torch.no_grad():
         out = mixer(q4, s4)
@@ -489,7 +549,7 @@ def test_fused_mixer_chain_vs_reference_and_unfused_path(tag, M, monkeypatch):
         assert torch.equal(mixer(q.detach(), s).cpu(), torch.from_numpy(y_f))
 
 
-@pytest.mark.parametrize("tag", ["3j4r_h64", "6j8r_h64"])
+@pytest.mark.parametrize("tag", ["3j4r_h64", "6j8r_h64", "12j16r_h64"])
 def test_bf16_mixer_error_bound_vs_reference(tag):
     """BASELINE.json config C5 ("bf16 mixer MFMA path"): hyper-network GEMMs with bf16 inputs / fp32 accumulation on the
     HIP device against the reference's fp32 Q_tot (G4 fixtures, incl. the weight set that saturates every clamp) and
@@ -778,7 +838,7 @@ def test_graphed_rollout_equals_eager_rollout():
             assert torch.equal(a, b), k
 
 
-@pytest.mark.parametrize("scenario,per_env", [("3j4r", False), ("3j4r", True), ("6j8r", False), ("2j2r_shipped", False)])
+@pytest.mark.parametrize("scenario,per_env", [("3j4r", False), ("3j4r", True), ("6j8r", False), ("2j2r_shipped", False), ("12j16r", False)])
 def test_fused_episode_rollout_vs_step_by_step(scenario, per_env):
     """The whole episode batch in three launches (ops.agent_episode: GRU cell + all-action Q-head + epsilon-greedy for all
     100 steps; env.step_many: all env steps as independent work items) against the step-by-step rollout with the same
@@ -1174,9 +1234,28 @@ def test_other_baseline_configs_end_to_end(scenario, E, H, mixer_dtype):
     np.random.seed(0)
     losses = [learner.train_from_buffer()["loss"] for _ in range(4)]
     assert all(np.isfinite(l) for l in losses)
-    # eager update on the same state agrees with the graphed path in kind (finite, same magnitude)
-    st = learner.train(buf.sample(32), {})
-    assert np.isfinite(st["loss"]) and 0.1 < st["loss"] / max(losses[-1], 1e-9) < 10
+    # The graph-replayed update against the eager learner.train() on the SAME episodes from the SAME state: the four
+    # statistics and the whole gradient vector at the G5 tolerances.  (The eager path itself is pinned on the reference's
+    # gradients at every one of these sizes: test_learner_on_gpu_matches_reference incl. 12j16r_h64, and on the NumPy
+    # oracle through tests/test_nets_cpu.py.)
+    idx = np.random.default_rng(1).choice(E, 32, replace=False)
+    snap = ([p_.detach().clone() for p_ in learner.params], learner._flat_exp_avg.clone(), learner._flat_exp_avg_sq.clone(),
+            learner._adam_step.clone(), learner.train_step, learner.last_target_update_step)
+    st_e = learner.train(buf.sample(32, indices=idx), {})
+    g_e = learner._flat_grad.clone()
+    with torch.no_grad():
+        for p_, q_ in zip(learner.params, snap[0]):
+            p_.copy_(q_)
+        learner._flat_exp_avg.copy_(snap[1]); learner._flat_exp_avg_sq.copy_(snap[2]); learner._adam_step.copy_(snap[3])
+    learner.train_step, learner.last_target_update_step = snap[4], snap[5]
+    learner._mark_body_shared()      # (the restore wrote the unchanged body values back)
+    st_g = learner.train_from_buffer(indices=idx)
+    g_g = learner._flat_grad.clone()
+    rt = 2e-2 if mixer_dtype == "bf16" else 1e-4     # (bf16 hyper-networks: 8 significant bits per product)
+    for k in st_e:
+        assert st_g[k] == pytest.approx(st_e[k], rel=rt, abs=TOL), k
+    scale = float(g_e.abs().max())
+    np.testing.assert_allclose(g_g.cpu().numpy(), g_e.cpu().numpy(), rtol=10 * rt, atol=(2e-5 if mixer_dtype != "bf16" else 2e-2) * max(scale, 1e-12))
 
 
 @pytest.mark.parametrize("B,T", [(32, 100), (4, 12), (3, 2)])
