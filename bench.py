@@ -165,6 +165,8 @@ def main():
     ap.add_argument("--jammers", type=int, default=3)
     ap.add_argument("--radars", type=int, default=4)
     ap.add_argument("--hidden", type=int, default=64)
+    ap.add_argument("--mixer-dtype", dest="mixer_dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16: BASELINE.json config 5's hyper-network option (library GEMMs with bf16 inputs; outside the 1e-5 bar)")
     ap.add_argument("--sweep", action="store_true", help="also print an E-sweep of the env kernel (stderr)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-modes", dest="no_other_modes", action="store_true",

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 
-def make_args(sc, hidden, device, batch_size=32, buffer_size=None, batch_envs=4096, seed=42):
+def make_args(sc, hidden, device, batch_size=32, buffer_size=None, batch_envs=4096, seed=42, mixer_dtype="fp32"):
     info = sc.env_info()
     return SimpleNamespace(
         n_agents=info["n_agents"], n_actions=info["n_actions"], state_shape=info["state_shape"],
@@ -29,7 +29,7 @@ def make_args(sc, hidden, device, batch_size=32, buffer_size=None, batch_envs=40
         rnn_hidden_dim=hidden, actor_hidden_dim=128, mixing_embed_dim=64, hyper_hidden_dim=128,
         lr=5e-6, gamma=0.99, grad_norm_clip=1.0, target_update_interval=200, batch_size=batch_size,
         buffer_size=buffer_size or 2 * batch_envs, epsilon_start=1.0, epsilon_finish=0.05, epsilon_anneal_time=100000,
-        device=str(device), use_cuda=True, seed=seed)
+        device=str(device), use_cuda=True, seed=seed, mixer_dtype=mixer_dtype)
 
 
 def _make_step_fn(cli, runner, learner, buf, args, T, mode, use_graphs, tails):
@@ -90,7 +90,7 @@ def make_step(cli, sc, env, dev, rank, world, mode):
     from .runners.episode_runner import BatchedEpisodeRunner
     from .utils.replay_buffer import EpisodeReplayBuffer
 
-    args = make_args(sc, cli.hidden, dev, batch_envs=env.batch_envs)
+    args = make_args(sc, cli.hidden, dev, batch_envs=env.batch_envs, mixer_dtype=getattr(cli, "mixer_dtype", "fp32"))
     gemm_tuning = False
     if not getattr(cli, "no_gemm_tuning", False):
         import tempfile
@@ -132,7 +132,9 @@ def make_step(cli, sc, env, dev, rank, world, mode):
              "train_calls_per_step": 1 if mode == "train" else 0,
              "updates_per_graph": (learner._g_multi[0] if (mode == "train" and use_graphs and learner._g_multi) else 1),
              "hip_graphs": bool(use_graphs), "gemm_tuning": bool(gemm_tuning),
-             "replay_capacity_episodes": args.buffer_size,
+             "replay_capacity_episodes": args.buffer_size, "mixer_dtype": args.mixer_dtype,
+             "mixer": ("one MFMA launch per direction (f32)" if (mode == "train" and learner.eval_qmix_net.fused_available(next(learner.eval_qmix_net.parameters())))
+                       else ("library GEMMs (%s) + tail kernel" % args.mixer_dtype)) if mode == "train" else None,
              "rollout": "fused: agent-episode launch + many-step env launch per episode batch" if fused_rollout else
                         ("HIP graph of the step-by-step rollout" if use_graphs else "eager step-by-step")}
     return step_fn, extra
