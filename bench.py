@@ -334,17 +334,17 @@ def main():
                           f"> as launched by the rollout: {Tn} steps x {E} envs = {Tn * E} work items per launch (macjd_env_step_many)",
                 "us_per_launch": round(ms_m * 1e3, 3),
                 "timing": "HIP events around 50 launches replayed from one HIP graph on their own stream (macjd_env_step_many_timed); "
-                          "the rocprofv3 kernel-trace summary of the rollout (profiles/r02*_bench_rollout_kernel_stats.csv) has the same kernel",
+                          "the committed rocprofv3 kernel-trace summary of this launch alone is quoted under 'profile'",
                 "traffic_measured_in_run": False,
-                "limiter": "VALU issue, not HBM: ~1043 VALU instructions per env-step (float64 SNR / detection-probability "
-                           "arithmetic incl. 7 exp, 2 Philox blocks) for 41 bytes; traffic = 1.01x algorithmic (DESIGN.md 4.1)",
+                "limiter": "VALU issue, not HBM: ~780 VALU instructions per env-step at 3j/4r (~190 float64 for the power / SNR "
+                           "quotients, 2 Philox blocks = 55 quarter-rate 32 x 32 multiplies, 7 float32 detection probabilities "
+                           "with a float64 fallback for compares within 2e-6) for 41 bytes; traffic = 1.01x algorithmic (DESIGN.md 4.1)",
                 "bytes_per_env_step": round(B_many, 2), "env_steps_per_launch": Tn * E,
                 "single_step_launch": single}
-    prof_m = profiled_kernel_time("env_step_kernel<", args.per_env, pattern="r*_bench_rollout_kernel_stats.csv")
+    prof_m = profiled_kernel_time("env_step_kernel<", args.per_env, pattern=f"r*_env_many_step_{J}j{R}r_kernel_stats.csv")
     if prof_m is not None and E == 4096 and not args.per_env:
         roofline["profile"] = {"file": prof_m[3], "avg_us": round(prof_m[0], 3), "min_us": round(prof_m[1], 3), "calls": prof_m[2],
-                               "note": "rollout-mode trace: the many-step launches plus bench.py's 2^22-env roofline launches share "
-                                       "this kernel name; min_us is the many-step launch"}
+                               "note": "rocprofv3 --kernel-trace --stats of scripts/replay_many_step.py: this launch alone"}
     del Tm, Pm, rew_m, ter_m, rd_m
     # large-batch point of the same kernel family (2^22 envs): the HBM-bound asymptote, measured every run so the
     # launch-bound fraction at the benchmark's E is not mistaken for the kernel's streaming rate

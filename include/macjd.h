@@ -161,6 +161,9 @@ typedef struct macjd_step_io {
 /* library / device */
 int         macjd_abi_version(void);
 const char* macjd_last_error(void);
+/* The library reads its MACJD_* environment switches (MACJD_ENV_REGULAR, MACJD_ENV_PD32, MACJD_GRU_SCAN) once, at the first
+ * launch; call this after changing one of them inside a running process (tests, A/B timing). */
+void        macjd_reload_options(void);
 int         macjd_device_count(void);   /* number of HIP devices, <0 on error */
 
 /* scenario handle: replaces ElectromagneticEnvironment.__init__/_initialize_entities

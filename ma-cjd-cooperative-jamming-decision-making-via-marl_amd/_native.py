@@ -20,7 +20,7 @@ STEP_LANE_KERNEL = 2
 STEP_SLOT_KERNEL = 4
 
 EXPORTS = [
-    "macjd_abi_version", "macjd_last_error", "macjd_device_count",
+    "macjd_abi_version", "macjd_last_error", "macjd_reload_options", "macjd_device_count",
     "macjd_scenario_create", "macjd_scenario_destroy", "macjd_scenario_dims", "macjd_scenario_is_regular",
     "macjd_env_reset", "macjd_env_step", "macjd_env_step_timed",
     "macjd_qhead_select", "macjd_gru_sequence", "macjd_mixer_tail_forward", "macjd_mixer_tail_backward",
@@ -304,6 +304,7 @@ def load() -> ctypes.CDLL:
     lib.macjd_abi_version.restype = ctypes.c_int
     lib.macjd_last_error.restype = ctypes.c_char_p
     lib.macjd_device_count.restype = ctypes.c_int
+    lib.macjd_reload_options.restype = None
     lib.macjd_scenario_create.restype = ctypes.c_int
     lib.macjd_scenario_create.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
     lib.macjd_scenario_destroy.restype = None
@@ -392,6 +393,11 @@ def load() -> ctypes.CDLL:
         raise NativeLibraryError(f"{LIB_NAME}: ABI version {lib.macjd_abi_version()} != expected {ABI_VERSION}")
     _lib = lib
     return lib
+
+
+def reload_options() -> None:
+    """Make the library re-read its MACJD_* environment switches (it reads them once, at the first launch)."""
+    load().macjd_reload_options()
 
 
 def check(rc: int, what: str) -> None:

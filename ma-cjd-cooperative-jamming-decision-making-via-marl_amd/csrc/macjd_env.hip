@@ -63,6 +63,24 @@ int set_err(int code, const char* fmt, const char* a) {
     return code;
 }
 
+// Process-wide switches of the env launches, read from the environment ONCE (macjd_reload_options re-reads them: tests
+// and A/B runs that change a switch inside one process).
+static EnvOptions g_env_options = {true, true, false};
+static bool g_env_options_loaded = false;
+static void load_env_options() {
+    const char* a = getenv("MACJD_ENV_REGULAR");
+    const char* b = getenv("MACJD_ENV_PD32");
+    const char* c = getenv("MACJD_GRU_SCAN");
+    g_env_options.regular = !(a && a[0] == '0');
+    g_env_options.pd32 = !(b && b[0] == '0');
+    g_env_options.gru_ksplit = c && !strcmp(c, "ksplit");
+    g_env_options_loaded = true;
+}
+const EnvOptions& env_options() {
+    if (!g_env_options_loaded) load_env_options();
+    return g_env_options;
+}
+
 // ---- detection probability, core/radar.py:67-82 (constants A, c1, denB precomputed on the host) -------------------
 // The two divisions of the formula are done with the hardware's own IEEE division algorithm MINUS its scaling /
 // special-case wrapper (v_div_scale x2, v_div_fmas' scale step, v_div_fixup): refined reciprocal r of the divisor (v_rcp +
@@ -139,6 +157,27 @@ __device__ __forceinline__ double det_prob(double snr, const PdConsts& k) {
     return p;
 }
 
+// PD32 (production variant on regular scenarios): the detection probability in float32 on the transcendental unit —
+// pd = 1 / (1 + 2^y), y = -log2(e) B = ky1 snr + ky0 (one fma, v_exp_f32, v_add, v_rcp_f32: 5 instructions instead of ~60
+// float64 ones incl. a 13-term exp polynomial and two refined reciprocals) — used where a value within 1e-5 is all the
+// consumer needs (the reward terms), and as a FILTER for the Monte-Carlo compares u <= pd: with |pd32 - pd| <= 4e-7
+// (argument rounding (|y| + |ky0|) 1.8e-7 times |dpd/dy| <= 0.173 pd (1 - pd) -> <= 1e-7; v_exp_f32 and v_rcp_f32 1 ulp each,
+// the add's rounding: <= 3e-7 together) and the float32 image of u within 1.2e-7, a compare whose two sides differ by more
+// than PD32_BOUND = 2e-6 has the same outcome in float64; the others (~4e-6 of all compares) evaluate the exact float64
+// chain.  FSM bits, hit decisions and therefore every integer output are those of the float64 kernel bit for bit; reward
+// terms differ from it by <= (R + J) 4e-7 (tested: bitwise-equal track / terminated, rewards within 1e-5, on the 70 000-env
+// edge batch).  MACJD_ENV_PD32=0 selects the all-float64 form.
+constexpr float PD32_BOUND = 2e-6f;
+struct Pd32Consts { float ky1, ky0; };
+__device__ __forceinline__ Pd32Consts pd32_consts(double A, double c1, double denB) {
+    const double l2e = 1.4426950408889634;
+    return Pd32Consts{(float)(-l2e * 10.0 / denB), (float)(-l2e * (10.0 * c1 - A) / denB)};
+}
+__device__ __forceinline__ float det_prob32(double snr, const Pd32Consts& k) {
+    const float y = __builtin_fmaf((float)snr, k.ky1, k.ky0);
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y));
+}
+
 // Uniform of (env e, slot) for the step that starts at `step_before` (include/macjd.h, macjd_step_io.u): supplied by the
 // caller, or word (slot & 3) of the env's Philox block (slot >> 2).  This on-demand form generates a whole block per
 // call; the kernels below generate each block they need ONCE per env-step and pick words out of it.
@@ -211,9 +250,10 @@ struct FastStepIO {
 // the guards that a regular scenario can never trigger (non-positive or tiny noise power, SNR < 0, the probability
 // formula's saturation selects) are not evaluated.  Same results bit for bit (tests: lane kernel vs (env x slot) kernel,
 // which keeps IEEE division and every guard, and both vs the oracle); 1285 -> ~1050 VALU instructions per env-step at 3j/4r.
-template <int JT, int RT, bool PE, bool FAST, class IO, bool REG = false>
+template <int JT, int RT, bool PE, bool FAST, class IO, bool REG = false, bool PD32 = false>
 __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restrict__ tb, const IO io) {
     static_assert(!REG || (FAST && !PE && JT && RT), "REG: production variant on shared tables, compiled sizes");
+    static_assert(!PD32 || REG, "PD32: float32 detection-probability filter of the regular production variant");
     constexpr int NJ = JT ? JT : MAXJ;
     constexpr int NR = RT ? RT : MAXR;
     const int J = JT ? JT : tb->J;
@@ -252,6 +292,7 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
 
     const double rp_min = tb->rp_min, rp_max = tb->rp_max;
     const PdConsts pdk = pd_consts(tb->pd_A, tb->pd_c1, tb->pd_denB);
+    const Pd32Consts pdk32 = pd32_consts(tb->pd_A, tb->pd_c1, tb->pd_denB);
     const int32_t episode_limit = tb->episode_limit;
     const bool arith32 = FAST ? true : ((io.P32 != nullptr) && !(io.flags & MACJD_STEP_ARITH_F64));
 
@@ -262,9 +303,9 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
         int32_t tt = 0;
         bool many = false, last_t = true;
         if constexpr (FAST) {
-            if (io.many_T > 0) {
+            if (io.many_T > 0) {   // grid = (envs / 256, steps): no division
                 many = true;
-                tt = (int32_t)(e_item / io.n_envs);
+                tt = (int32_t)blockIdx.y;
                 e = e_item - (int64_t)tt * io.n_envs;
                 last_t = (tt == io.many_T - 1);
             }
@@ -512,7 +553,53 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
                 snr_w[r] = (den > 1e-18) ? t_GaPs(r) / den : 0.0;            // :332
             }
         }
-        if (REG) det_prob_batch_regular<NP>(snr_all, pd_all, pdk);           // :337, :425
+        // PD32: all R + J compares u <= pd decided here — by the float32 value where the two sides are further apart than
+        // its error bound, by ONE shared copy of the exact float64 chain (a rarely taken loop) for the others
+        uint32_t le_bits = 0;
+        float pd32f[PD32 ? NP : 1];   // (kept as float32 until used: 7 registers instead of 14)
+        auto pd_at = [&](int i) -> double { return PD32 ? (double)pd32f[PD32 ? i : 0] : pd_all[i]; };
+        if constexpr (PD32) {
+            uint32_t w_all[NP];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) w_all[r] = rw[r];
+            {
+                int nd = 0;   // RNG slot of jammer j's valid deception action: R + (valid deception actions before it)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    uint32_t w = rw[NR];
+#pragma unroll
+                    for (int k = 1; k < NJ; ++k) w = (nd == k) ? rw[NR + k] : w;
+                    w_all[NR + j] = w;
+                    nd += (dec_tgt[j] >= 0) ? 1 : 0;
+                }
+            }
+            uint32_t close_bits = 0;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const float p32 = det_prob32(snr_all[i], pdk32);
+                pd32f[i] = p32;
+                const float d = __builtin_fmaf((float)w_all[i], 0x1p-32f, 0x1p-33f) - p32;
+                const bool need = (i < NR) || (dec_tgt[i < NR ? 0 : i - NR] >= 0);
+                le_bits |= (d <= 0.0f) ? (1u << i) : 0u;
+                close_bits |= (need && fabsf(d) <= PD32_BOUND) ? (1u << i) : 0u;
+            }
+            if (close_bits) {
+#pragma unroll 1
+                for (int i = 0; i < NP; ++i) {
+                    if (!((close_bits >> i) & 1u)) continue;
+                    double snr_i = snr_all[0];
+                    uint32_t w_i = w_all[0];
+#pragma unroll
+                    for (int k = 1; k < NP; ++k) {
+                        snr_i = (i == k) ? snr_all[k] : snr_i;
+                        w_i = (i == k) ? w_all[k] : w_i;
+                    }
+                    double p;
+                    det_prob_batch_regular<1>(&snr_i, &p, pdk);
+                    le_bits = (u32_mid(w_i) <= p) ? (le_bits | (1u << i)) : (le_bits & ~(1u << i));
+                }
+            }
+        } else if (REG) det_prob_batch_regular<NP>(snr_all, pd_all, pdk);    // :337, :425
         else if (PRE) det_prob_batch<NP>(snr_all, pd_all, pdk);
 
         // ---- deception: Monte-Carlo detection of the false targets in jammer order, environment.py:425-447 ----
@@ -520,18 +607,20 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const bool is_dec = dec_tgt[j] >= 0;
-                double u;
+                double u = 2.0;
+                uint32_t w = 0;
                 if (own_rng) {
-                    uint32_t w = rw[NR];
+                    w = rw[NR];
 #pragma unroll
                     for (int k = 1; k < NJ; ++k) w = (n_dec == k) ? rw[NR + k] : w;
-                    u = u32_mid(w);
+                    if (!PD32) u = u32_mid(w);
                 } else {
                     u = is_dec ? io.u[e * io.u_se + (int64_t)(R + n_dec) * io.u_sx] : 2.0;
                 }
                 n_dec += is_dec ? 1 : 0;
-                const double pd_f = pd_all[NR + j];
-                const bool hit = is_dec && (u <= pd_f);                      // :430-434
+                const double pd_f = pd_at(NR + j);
+                const bool hit = PD32 ? (is_dec && ((le_bits >> (NR + j)) & 1u))
+                                      : (is_dec && (u <= pd_f));             // :430-434
                 const double safe = pd_f < 0.999999 ? pd_f : 0.999999;      // :446
                 hit_mask |= hit ? (1u << dec_tgt[j]) : 0u;
                 if (SCAT) {
@@ -551,9 +640,14 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             if (!RT && r >= R) break;
-            const double pd = PRE ? pd_all[r] : det_prob(snr_w[r], pdk);    // :337
-            const double u = (PRE && own_rng) ? u32_mid(rw[r]) : draw_uniform<FAST>(io, e, episode, r, (uint32_t)step_before);
-            const bool detected = (u <= pd);                                   // :341
+            const double pd = PRE ? pd_at(r) : det_prob(snr_w[r], pdk);     // :337
+            bool detected;
+            if constexpr (PD32) {
+                detected = (le_bits >> r) & 1u;                                // :341
+            } else {
+                const double u = (PRE && own_rng) ? u32_mid(rw[r]) : draw_uniform<FAST>(io, e, episode, r, (uint32_t)step_before);
+                detected = (u <= pd);                                          // :341
+            }
             // radar.py:102-117: SEARCH & detected -> TRACK, SEARCH & !detected -> SEARCH,
             // TRACK & !detected -> SEARCH, TRACK & detected -> TRACK.  The next state therefore
             // equals `detected` whatever the previous state was, so the previous state is never
@@ -603,8 +697,8 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
     if constexpr (FAST) {
         // one env per lane, no grid-stride loop: inside a loop every argument and table constant is loop-invariant,
         // gets hoisted and stays live for the whole body (SGPR spills); straight-line code loads them where used
-        const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        if (item < io.n_envs * (io.many_T > 0 ? io.many_T : 1)) env_step_one(item);
+        const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (env < io.n_envs) env_step_one(env + (int64_t)blockIdx.y * io.n_envs);   // (blockIdx.y = step of a many-step launch)
     } else {
         for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < io.n_envs;
              e += (int64_t)gridDim.x * blockDim.x)
@@ -908,6 +1002,8 @@ extern "C" {
 int macjd_abi_version(void) { return MACJD_ABI_VERSION; }
 const char* macjd_last_error(void) { return macjd::g_err; }
 
+void macjd_reload_options(void) { macjd::load_env_options(); }
+
 int macjd_device_count(void) {
     int n = 0;
     hipError_t err = hipGetDeviceCount(&n);
@@ -1052,7 +1148,9 @@ static int launch_step(const macjd_scenario* s, const macjd_step_io* io, hipStre
         // large batches: 256-lane workgroups, grid-stride, tables staged once per workgroup.
         const int block = (E >= (1 << 16)) ? 256 : 64;
         int64_t grid = (E + block - 1) / block;
-        const dim3 gf((unsigned)grid), b(block);   // production variants: one env per lane, no grid-stride loop
+        // production variants: one env per lane, no grid-stride loop; many-step launches: grid = (envs / block, steps)
+        if (many_T > 65535) return set_err(MACJD_EINVAL, "%s", "macjd_env_step_many: at most 65535 steps per launch");
+        const dim3 gf((unsigned)(many_T > 0 ? (io->n_envs + block - 1) / block : grid), (unsigned)(many_T > 0 ? many_T : 1)), b(block);
         const int64_t cap = (block == 256) ? 256 * 8 : 256 * 16;
         if (grid > cap) grid = cap;
         const dim3 g((unsigned)grid);
@@ -1086,14 +1184,16 @@ static int launch_step(const macjd_scenario* s, const macjd_step_io* io, hipStre
             return set_err(MACJD_EUNSUPPORTED, "%s", "macjd_env_step_many: production configuration only (Philox uniforms, "
                            "float32 actions, no float64 diagnostics, offsets below 2^32 bytes)");
         }
-        const char* reg_env = getenv("MACJD_ENV_REGULAR");   // "0": keep IEEE divisions + all guards (A/B runs, tests)
-        const bool no_reg = reg_env && reg_env[0] == '0';
+        const bool no_reg = !macjd::env_options().regular;   // MACJD_ENV_REGULAR=0: keep IEEE divisions + all guards
+        const bool pd32 = macjd::env_options().pd32;          // MACJD_ENV_PD32=0: all-float64 detection probabilities
 #define MACJD_LAUNCH(JT, RT)                                                                                          \
     do {                                                                                                              \
         if (per_env && fast)                                                                                          \
             hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT, true, true, macjd::FastStepIO>), gf, b, 0, stream, s->dev, f);      \
         else if (per_env)                                                                                             \
             hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT, true, false, macjd_step_io>), g, b, 0, stream, s->dev, *io);        \
+        else if (fast && s->host.regular && !no_reg && pd32)                                                          \
+            hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT, false, true, macjd::FastStepIO, true, true>), gf, b, 0, stream, s->dev, f); \
         else if (fast && s->host.regular && !no_reg)                                                                  \
             hipLaunchKernelGGL((macjd::env_step_kernel<JT, RT, false, true, macjd::FastStepIO, true>), gf, b, 0, stream, s->dev, f); \
         else if (fast)                                                                                                \

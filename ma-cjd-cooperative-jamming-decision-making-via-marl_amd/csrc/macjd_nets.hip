@@ -648,8 +648,7 @@ extern "C" int macjd_gru_sequence(const macjd_gru_io* io, void* hip_stream) {
     const dim3 g((unsigned)(io->B * io->J), (unsigned)io->n_nets, actor ? 2u : 1u);
     hipStream_t s = (hipStream_t)hip_stream;
     // H = 64: the unit-split scan; MACJD_GRU_SCAN=ksplit keeps the K-split form (A/B runs, tests compare the two)
-    const char* scan_env = getenv("MACJD_GRU_SCAN");   // read per call: a test switches it inside one process
-    const bool ksplit = scan_env && !strcmp(scan_env, "ksplit");
+    const bool ksplit = env_options().gru_ksplit;   // (read once; macjd_reload_options() after changing it in-process)
     if (io->H == 64 && !ksplit) {
         if (io->obs || io->reserved) hipLaunchKernelGGL(gru_sequence_units_kernel<true>, g, dim3(256), 0, s, *io);
         else hipLaunchKernelGGL(gru_sequence_units_kernel<false>, g, dim3(256), 0, s, *io);

@@ -51,6 +51,8 @@ def _teardown_graphs_after_every_gpu_test(request):
         return
     import gc
     import torch
+    from macjd_amd import _native
+    _native.reload_options()   # (the previous test may have changed a MACJD_* switch through monkeypatch)
     gc.collect()
     gc.disable()
     try:

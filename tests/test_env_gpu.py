@@ -254,12 +254,18 @@ def test_every_episode_draws_fresh_monte_carlo_values():
         assert whole.episode_index.cpu().tolist() == ora.episode.tolist()
 
 
+@pytest.mark.parametrize("pd32", [False, True])
 @pytest.mark.parametrize("name,E,n", [("3j4r", 777, 23), ("6j8r", 300, 7), ("2j2r_shipped", 64, 100)])
-def test_many_step_launch_equals_step_by_step(name, E, n):
-    """macjd_env_step_many: the n steps of an episode batch as ONE launch over n x E independent work items (the FSM's
+def test_many_step_launch_equals_step_by_step(name, E, n, pd32, monkeypatch):
+    """(pd32: the many-step launch's float32 detection-probability filter, the default — integer outputs and everything
+    derived from them alone stay bit for bit, the reward's probability terms move by <= (R + J) 4e-7; off: all float64,
+    every output bit for bit.)  macjd_env_step_many: the n steps of an episode batch as ONE launch over n x E independent work items (the FSM's
     next state does not depend on the previous one, core/radar.py:102-117, so given the actions of all steps the env-steps
     are independent) == n single-step launches, bit for bit: rewards, terminated, (r_d, r_p, r_j) per step and summed,
     final FSM state, step counters; also across an episode boundary of the counters and against the oracle."""
+    from macjd_amd import _native
+    monkeypatch.setenv("MACJD_ENV_PD32", "1" if pd32 else "0")
+    _native.reload_options()
     sc, _ = load_scenario(name)
     R, J = sc.num_radars, sc.num_jammers
     rng = np.random.default_rng(E + n)
@@ -283,8 +289,14 @@ def test_many_step_launch_equals_step_by_step(name, E, n):
         rewn = torch.zeros((n, E, 1), device="cuda"); tern = torch.zeros((n, E, 1), dtype=torch.bool, device="cuda")
         rdn = torch.zeros((n, E, 3), device="cuda"); sumn = torch.zeros((E, 3), device="cuda")
         many.step_many(Td.view(n, E, J, 1), Pd.view(n, E, J, 1), rewn, tern, rdn, rdpj_sum=sumn)
-        assert torch.equal(rewn.view(n, E), rew1) and torch.equal(tern.view(n, E).to(torch.uint8), ter1)
-        assert torch.equal(rdn, rd1) and torch.equal(sumn, sum1)
+        assert torch.equal(tern.view(n, E).to(torch.uint8), ter1)
+        if pd32:
+            tol = (R + J) * 4e-7 + 1e-7
+            assert torch.equal(rdn[..., :2], rd1[..., :2])                       # r_d (FSM bits), r_p: no probability value
+            assert float((rdn[..., 2] - rd1[..., 2]).abs().max()) <= tol and float((rewn.view(n, E) - rew1).abs().max()) <= tol
+            assert float((sumn - sum1).abs().max()) <= n * tol
+        else:
+            assert torch.equal(rewn.view(n, E), rew1) and torch.equal(rdn, rd1) and torch.equal(sumn, sum1)
         assert torch.equal(many.track, one.track) and torch.equal(many.step_count, one.step_count)
         assert int(many.step_count.min()) == n and torch.equal(many.episode_index, one.episode_index)
     with pytest.raises(ValueError):
@@ -442,11 +454,13 @@ def test_per_env_tables_other_sizes_vs_oracle(J, R, tiled, monkeypatch):
 
 @pytest.mark.parametrize("per_env", [False, True])
 @pytest.mark.parametrize("J,R", [(3, 4), (6, 8), (12, 16), (2, 2)])
-def test_fast_kernel_variant_equals_general_variant(J, R, per_env):
+def test_fast_kernel_variant_equals_general_variant(J, R, per_env, monkeypatch):
     """The compile-time production variant of the lane kernel (Philox uniforms, float32 actions, no float64
-    diagnostics) == the general variant (selected here by asking for the diagnostics), bitwise, shared and per-env
-    tables."""
+    diagnostics; all-float64 probabilities: MACJD_ENV_PD32=0) == the general variant (selected here by asking for the
+    diagnostics), bitwise, shared and per-env tables."""
     from macjd_amd import _native
+    monkeypatch.setenv("MACJD_ENV_PD32", "0")
+    _native.reload_options()
     from macjd_amd.scenario import Scenario, ScenarioBatch, ring_scenario_dict
     from macjd_amd.simulation.environment import BatchedElectromagneticEnvironment
     E = 300
@@ -520,28 +534,52 @@ def test_regular_scenario_variant_equals_ieee_division_variant(name, monkeypatch
     sc, _ = load_scenario(name)
     R, J = sc.num_radars, sc.num_jammers
     E = 70000 if name in ("3j4r", "3j3r_edge") else 20000
-    reg, ieee = _env(sc, E, seed=21, env_offset=5), _env(sc, E, seed=21, env_offset=5)
+    reg32, reg, ieee = (_env(sc, E, seed=21, env_offset=5) for _ in range(3))
     assert reg.scenario_regular, "the shipped / benchmark / edge scenarios are regular"
-    reg.kernel_flags = ieee.kernel_flags = _native.STEP_LANE_KERNEL
-    reg.reset(); ieee.reset()
+    reg32.kernel_flags = reg.kernel_flags = ieee.kernel_flags = _native.STEP_LANE_KERNEL
+    reg32.reset(); reg.reset(); ieee.reset()
     ora = OracleEnv(sc, 4096, n_threads=8)
     ora.reset()
     rng = np.random.default_rng(J * 100 + R)
+
+    def options(**kv):     # the library reads its switches once: re-read after every change
+        for k in ("MACJD_ENV_REGULAR", "MACJD_ENV_PD32"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in kv.items():
+            monkeypatch.setenv(k, v)
+        _native.reload_options()
+
+    worst = 0.0
     for t in range(6):
         T, P = random_actions(rng, E, J, R)
         P = (P * 1.6 - 0.3).astype(np.float32)          # some below 0 and above 1 (np.clip)
         P[rng.random((E, J)) < 0.01] = np.nan           # NaN propagates through np.clip: the jammer is not recorded
         Td, Pd = torch.from_numpy(T).cuda(), torch.from_numpy(P).cuda()
-        monkeypatch.delenv("MACJD_ENV_REGULAR", raising=False)
+        options()                                        # production: regular forms + float32 probability filter
+        r0, t0, i0 = reg32.step(Td, Pd)
+        options(MACJD_ENV_PD32="0")                      # regular forms, all-float64 probabilities
         r1, t1, i1 = reg.step(Td, Pd)
-        monkeypatch.setenv("MACJD_ENV_REGULAR", "0")
+        options(MACJD_ENV_REGULAR="0")                   # IEEE divisions and every guard
         r2, t2, i2 = ieee.step(Td, Pd)
+        options()
         same = lambda a, b: torch.equal(torch.nan_to_num(a.float(), nan=-777.0), torch.nan_to_num(b.float(), nan=-777.0))
         assert torch.isnan(r1).any()                     # a NaN power makes r_p (and the reward) NaN, like the reference
         assert same(r1, r2) and torch.equal(t1, t2)
         for k in ("r_d", "r_p", "r_j", "radar_tracking", "radar_pds", "snr_with_jamming"):
             assert same(i1[k], i2[k]), (t, k)
+        # the float32 filter: every integer output and everything that depends on them alone bit for bit; the reward's
+        # probability terms within the stated bound
+        assert torch.equal(t0, t1) and torch.equal(i0["radar_tracking"], i1["radar_tracking"]), t
+        for k in ("r_d", "r_p", "snr_with_jamming"):
+            assert same(i0[k], i1[k]), (t, k)
+        fin = torch.isfinite(r1)
+        assert torch.equal(torch.isfinite(r0), fin)
+        for a_, b_ in ((r0, r1), (i0["r_j"], i1["r_j"])):
+            worst = max(worst, float((a_[fin].double() - b_[fin].double()).abs().max()))
+        worst = max(worst, float((i0["radar_pds"].double() - i1["radar_pds"].double()).abs().max()))
         ora.step_count[:] = t
         o = ora.step(T[:4096], P[:4096], seed=21, env_offset=5)
         np.testing.assert_allclose(r1[:4096].cpu().numpy(), o["reward"], rtol=0, atol=1e-5)
         np.testing.assert_array_equal(i1["radar_tracking"][:4096].cpu().numpy(), o["track"])
+        np.testing.assert_allclose(r0[:4096].cpu().numpy(), o["reward"], rtol=0, atol=1e-5)
+    assert worst <= (R + J) * 4e-7 + 1e-7, worst          # (float32 outputs: + half an ulp of the reward)

@@ -400,7 +400,8 @@ def test_fused_rollout_kernel_reproduces_reference_greedy_episodes():
     all 100 steps in one launch) + env.step_many — on E = 16 replicas of the one env.  The observation is static, so the
     greedy action sequence depends on the agent alone: actions bit-exact in every replica, chosen powers within 1e-5; the
     deterministic reward term (avg_r_p), the mean power and the action distribution equal the reference's run_info; the
-    Monte-Carlo terms are compared with the step-by-step env.step() on the same actions (same Philox streams: bitwise)."""
+    Monte-Carlo terms are compared with the step-by-step env.step() on the same actions (same Philox streams, same
+    decisions: rewards within 1e-5, terminated flags identical)."""
     from macjd_amd.core.mac import BasicMAC
     from macjd_amd.runners.episode_runner import BatchedEpisodeRunner
     from macjd_amd.scenario import Scenario
@@ -446,10 +447,7 @@ def test_fused_rollout_kernel_reproduces_reference_greedy_episodes():
         for t in range(T):
             rew, term, _ = env2.step(torch.from_numpy(np.broadcast_to(ref_T[t].astype(np.int32), (E, J)).copy()).to(DEV),
                                      torch.from_numpy(np.broadcast_to(ref_P[t].astype(np.float32), (E, J)).copy()).to(DEV))
-            if np.array_equal(got_P[t], np.broadcast_to(ref_P[t].astype(np.float32), (E, J))):   # (bitwise-equal powers)
-                assert torch.equal(st["reward"][t].view(E), rew), (ep, t)
-            else:
-                np.testing.assert_allclose(st["reward"][t].view(E).cpu().numpy(), rew.cpu().numpy(), atol=TOL, rtol=0)
+            np.testing.assert_allclose(st["reward"][t].view(E).cpu().numpy(), rew.cpu().numpy(), atol=TOL, rtol=0)
             assert torch.equal(st["terminated"][t].view(E), term)
 
 
@@ -608,6 +606,8 @@ def test_gru_sequence_kernel(H, B, T, J, scan, monkeypatch):
         if H != 64:
             pytest.skip("H = 128 has the K-split kernel only")
         monkeypatch.setenv("MACJD_GRU_SCAN", "ksplit")
+        from macjd_amd import _native
+        _native.reload_options()
     rng = np.random.default_rng(H + T)
     gis = [torch.tensor(rng.standard_normal((B, T, J, 3 * H)), dtype=torch.float32) for _ in range(2)]
     ws = [torch.tensor(rng.standard_normal((3 * H, H)) / np.sqrt(H), dtype=torch.float32) for _ in range(2)]
@@ -890,7 +890,9 @@ def test_fused_episode_rollout_vs_step_by_step(scenario, per_env):
     agree = same.all(dim=2).squeeze(-1)                                              # [N, T]: all agents agree
     pa, pb = B["actions_continuous"]
     assert torch.equal(pa[same], pb[same])
-    assert torch.equal(B["reward"][0].squeeze(-1)[agree], B["reward"][1].squeeze(-1)[agree])
+    # (the many-step launch decides the Monte-Carlo compares through its float32 probability filter: same decisions, reward
+    # terms within (R + J) 4e-7 of the all-float64 single-step launches)
+    assert float((B["reward"][0].squeeze(-1)[agree] - B["reward"][1].squeeze(-1)[agree]).abs().max()) <= 1e-5
     assert torch.equal(B["terminated"][0], B["terminated"][1]) and torch.equal(B["filled"][0], B["filled"][1])
     for k in ("state", "obs", "avail_actions"):
         assert torch.equal(*B[k]), k
@@ -1006,6 +1008,8 @@ def test_gru_scan_with_in_kernel_input_transform_and_actor(tag, scan, monkeypatc
         if H != 64:
             pytest.skip("H = 128 has the K-split kernel only")
         monkeypatch.setenv("MACJD_GRU_SCAN", "ksplit")
+        from macjd_amd import _native
+        _native.reload_options()
     torch.manual_seed(2)
     with quiet():
         agents = [RNNAgent(S, args).to(DEV), RNNAgent(S, args).to(DEV)]
