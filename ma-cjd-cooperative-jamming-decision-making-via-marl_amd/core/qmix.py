@@ -219,9 +219,14 @@ class QMixLearner:
         for p, off in zip(tr, offs):
             p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
 
-    def _allreduce_grads(self):
+    def _ar_capturable(self):
+        """The gradient all-reduce can be recorded into a HIP graph: an initialised RCCL process group."""
         import torch.distributed as dist
-        if self._world_size() <= 1:
+        return dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
+
+    def _allreduce_grads(self, force=False):
+        import torch.distributed as dist
+        if self._world_size() <= 1 and not (force and self._ar_capturable()):   # (force: a one-rank group still issues it)
             return
         if dist.get_backend() == "nccl":   # RCCL averages in the collective: no separate divide launch
             dist.all_reduce(self._flat_grad, op=dist.ReduceOp.AVG)
@@ -567,7 +572,8 @@ class QMixLearner:
         return getattr(self, "_grad_norm", None)
 
     # ------------------------------------------------------------------ HIP-graph path
-    def enable_graphs(self, buffer, batch_size, warmup_iters=3, force_two_graphs=False, updates_per_graph=None):
+    def enable_graphs(self, buffer, batch_size, warmup_iters=3, force_two_graphs=False, updates_per_graph=None,
+                      graphed_allreduce=None):
         """Capture the update as two HIP graphs around the (eager) gradient all-reduce (ONE graph holding both halves
         when there is a single process, i.e. nothing to all-reduce):
           graph A  gather the sampled episodes from the device replay (static index tensor) + both
@@ -660,7 +666,15 @@ class QMixLearner:
         self._graph_a, self._graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # a single process has no all-reduce between the two halves: one graph, one launch per update
         # (force_two_graphs: the layout every rank of a multi-GPU job runs, for single-process tests)
-        self._g_single = self._world_size() <= 1 and not force_two_graphs
+        # With ranks (RCCL): MACJD_GRAPHED_ALLREDUCE=1 captures the gradient all-reduce INSIDE the update graph —
+        # torch.distributed records collectives issued on a capturing stream into the capture (the collective runs on the
+        # process group's own stream, joined to the capture by events) — so ranks replay ONE graph per update, or per
+        # group of K updates, like a single process does, instead of graph A -> eager all-reduce -> graph B.  Off by
+        # default: no multi-GPU node was available to run it on; only its capture / replay
+        # mechanics are tested, with a one-rank RCCL group (tests/test_dist_gpu.py).
+        self._g_graphed_ar = bool(graphed_allreduce if graphed_allreduce is not None
+                                  else os.environ.get("MACJD_GRAPHED_ALLREDUCE", "0") == "1") and self._ar_capturable()
+        self._g_single = (self._world_size() <= 1 and not force_two_graphs) or self._g_graphed_ar
         with hipgraph.capture(self._graph_a):
             self._g_out_a = body_a()
             # the four logged scalars of an update end up in ONE static [4] tensor: the loss kernel writes (loss,
@@ -672,6 +686,8 @@ class QMixLearner:
             self._g_stats4 = st4 if (st4 is not None and st4.numel() == 4) else None
             nxt = (self._g_idx, self._g_n_stored, self._g_draws, self._sampler_seed()) if self._g_dev_sampler else None
             if self._g_single:
+                if self._g_graphed_ar:
+                    self._allreduce_grads(force=True)
                 self._g_out_b = self._clip_and_step(sample_next=nxt)
         if not self._g_single:
             with hipgraph.capture(self._graph_b, pool=self._graph_a.pool()):
@@ -734,6 +750,8 @@ class QMixLearner:
                     nxt_batch = box.get("next")
                     rows.append(self._last_stats4)          # this update's (loss, mean Q_tot, mean target, grad norm)
                     self._grad_norm = rows[-1][3]
+                    if self._g_graphed_ar:
+                        self._allreduce_grads(force=True)
                     # the update's last launch draws the next batch — unless the prefetch behind the join has done so
                     self._clip_and_step(sample_next=None if nxt_batch is not None else nxt)
                 if pipelined:

@@ -90,3 +90,36 @@ def test_two_ranks_graphed_update_equals_single_process_on_the_global_batch(tmp_
     # equal filled-step counts on both ranks => mean of the rank gradients == the global-batch gradient; Adam's
     # m / sqrt(v) amplifies summation-order noise of near-zero entries, hence 2e-5 (as in the graph-vs-eager test)
     np.testing.assert_allclose(flat, w0, rtol=0, atol=2e-5)
+
+
+def _graphed_allreduce_worker(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    _, plain, buf_p = _build(seed=7)
+    _, graphed, buf_g = _build(seed=7)
+    plain.enable_graphs(buf_p, B, updates_per_graph=2, graphed_allreduce=False)
+    graphed.enable_graphs(buf_g, B, updates_per_graph=2, graphed_allreduce=True)
+    assert graphed._g_graphed_ar and graphed._g_single and graphed._g_multi[0] == 2
+    assert not plain._g_graphed_ar
+    plain.train_from_buffer_many(5)
+    graphed.train_from_buffer_many(5)
+    torch.cuda.synchronize()
+    a = torch.cat([p.detach().reshape(-1) for p in plain._trainable()]).cpu().numpy()
+    b = torch.cat([p.detach().reshape(-1) for p in graphed._trainable()]).cpu().numpy()
+    np.save(os.path.join(out_dir, "plain.npy"), a)
+    np.save(os.path.join(out_dir, "graphed.npy"), b)
+    graphed.release_graphs()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_captured_inside_the_update_graph(tmp_path):
+    """MACJD_GRAPHED_ALLREDUCE / enable_graphs(graphed_allreduce=True): the RCCL all-reduce of the flat gradient vector is
+    recorded into the update's HIP graph, so ranks keep the one-graph-per-update and K-updates-per-graph replay of a
+    single process.  A one-GPU box can only host a ONE-rank RCCL group: this checks the mechanics — the collective is
+    captured, grouped replays work, the (identity) all-reduce leaves the update sequence bit for bit — not the exchange
+    between ranks (tests/test_dist_cpu.py and the two-rank gloo test above cover the arithmetic of that)."""
+    mp.spawn(_graphed_allreduce_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    np.testing.assert_array_equal(np.load(tmp_path / "plain.npy"), np.load(tmp_path / "graphed.npy"))
