@@ -33,7 +33,7 @@ import torch
 import torch.nn.functional as F
 import torch.optim as optim
 
-from .. import hipgraph, ops
+from .. import hipgraph, ops, options
 from .networks import QMixer
 
 
@@ -86,15 +86,28 @@ class QMixLearner:
     def _mark_body_shared(self):
         """Record that the two controllers' bodies hold identical values right now (after the deep copy in the
         constructor and after every hard target sync).  ``_body_is_shared`` stays true until any of those tensors is
-        written again (their autograd version counters move): another optimiser training the body, a checkpoint loaded
+        written again (their autograd version counters move; a write through ``p.data`` does NOT move them — enable_graphs
+        therefore compares the values, _verify_body_shared): another optimiser training the body, a checkpoint loaded
         into one controller only, ...  The reference's own learner never changes them (qmix.py:161-184: the loss only
         reaches fc2_q_head and the mixer), so in reference-faithful training the eval and target unrolls share one
         input transform, one GRU scan and one actor chain for ever."""
         pe, pt = self._body_params(self.mac.agent), self._body_params(self.target_mac.agent)
         self._body_versions = [(p, p._version, q, q._version) for p, q in zip(pe, pt)]
 
+    def _verify_body_shared(self):
+        """The version counters miss writes made through ``p.data`` (or any other alias created before the mark).  Where it
+        is cheap — enable_graphs, not the update — the VALUES are compared: returns whether the two bodies are identical
+        now and brings the bookkeeping in line with that (marks them shared again, or forgets the mark)."""
+        pe, pt = self._body_params(self.mac.agent), self._body_params(self.target_mac.agent)
+        same = len(pe) == len(pt) and all(p.shape == q.shape and torch.equal(p.detach(), q.detach()) for p, q in zip(pe, pt))
+        if same:
+            self._mark_body_shared()
+        else:
+            self._body_versions = None
+        return same and self._body_is_shared()
+
     def _body_is_shared(self):
-        if os.environ.get("MACJD_SHARED_BODY", "1") == "0" or not self._body_versions:
+        if not options.on("SHARED_BODY") or not self._body_versions:
             return False
         pe = self._body_params(self.mac.agent)
         if len(pe) != len(self._body_versions):
@@ -332,7 +345,7 @@ class QMixLearner:
         # ONE scan and ONE actor chain serve both networks; only the Q-heads differ.
         shared = self._body_is_shared()
         body = macs[1].agent   # the network whose body is evaluated when shared
-        fused_dq = os.environ.get("MACJD_FUSED_DOUBLEQ", "1") != "0" and ops.qhead_double_q_fused_supported(rows, H, A)
+        fused_dq = ops.qhead_double_q_fused_supported(rows, H, A)
         # Static observations (the replay buffer knows: every stored episode came from an env whose observation does not
         # change within an episode): everything of the agent that reads only the observation — the fc1 -> W_ih input
         # transform and the actor chain — is evaluated on the B * J step-0 rows instead of on all B * (T + 1) * J rows;
@@ -402,14 +415,13 @@ class QMixLearner:
                 validate=False).view(B, T1, J)                                                  # qmix.py:161-184
             return self.eval_qmix_net(q_taken, st["state"])                                    # [B,T+1,1], qmix.py:187
 
-        two_streams = dev.type == "cuda" and os.environ.get("MACJD_UPDATE_STREAMS", "2") != "1"
+        two_streams = dev.type == "cuda" and options.get("UPDATE_STREAMS") != "1"
         # A prefetched update (pipelined group) has the scan's outputs at its very start, so its whole TARGET branch —
         # Double-DQN launch and target mixer, which read the scan, the Q-heads and the target mixer but nothing of the eval
         # head — runs on the side stream BESIDE the eval head (taken-action Q-head + eval mixer on this stream) instead
         # of behind it; the two meet at the TD loss.  (-22 us of a 147 us update.)
         target_beside_head = (two_streams and prefetched is not None and fused_dq and pre_actor is not None
-                              and self.target_qmix_net.fused_available(st["state"])
-                              and os.environ.get("MACJD_TARGET_BESIDE_HEAD", "1") != "0")
+                              and self.target_qmix_net.fused_available(st["state"]))
         if target_beside_head:
             origin = torch.cuda.current_stream(dev)
             ts = self._target_stream
@@ -491,8 +503,7 @@ class QMixLearner:
             # (Measured and dropped: the loss inside the eval mixer's backward launch — its loads and reductions in front of
             # the kernel's chain cost the 7 us the separate launch does: 26.2 vs 7.5 + 17.8 us.)
             stats_done = None
-            if (tot_m is not None and os.environ.get("MACJD_TD_GRAD_IN_MIXER", "1") != "0"
-                    and ops.fused_mixer_backward_will_run(eval_q_tot)):
+            if tot_m is not None and ops.fused_mixer_backward_will_run(eval_q_tot):
                 # pipelined update: the batch's mask sum was computed behind its gather, so the eval mixer's backward
                 # launch forms dL/dQ_tot itself (5 loads per row) and the loss launch leaves the serial chain: it still runs
                 # — for the logged sums — on the side stream, ordered before the optimiser writes the gradient norm into
@@ -515,7 +526,7 @@ class QMixLearner:
             # the weight gradients: one grouped launch pair after the chain, written into the flat gradient vector
             # (single process: the LayerNorm-parameter launch behind the grouped products is held back and evaluated
             # inside the optimiser step's squared-norm launch — with more ranks the all-reduce needs it done first)
-            hold = self._flat_param is not None and self._world_size() <= 1 and os.environ.get("MACJD_LN_IN_SQNORM", "1") != "0"
+            hold = self._flat_param is not None and self._world_size() <= 1 and options.on("LN_IN_SQNORM")
             with ops.deferred_wgrad(grad_dst=getattr(self, "_grad_dst", None), hold_lnparam=hold) as dw:
                 eval_q_tot.backward(gy)
             assert ops._PENDING_TD is None, "the fused mixer's backward did not take the TD loss's inputs"
@@ -586,15 +597,15 @@ class QMixLearner:
         if self.device.type != "cuda":
             raise RuntimeError("enable_graphs needs the learner on a HIP device")
         self.release_graphs()   # a re-capture destroys the previous graphs first, explicitly and at a quiet point
+        self._verify_body_shared()   # (values, not version counters: catches writes made through .data)
         same_buffer = getattr(self, "_g_buffer", None) is buffer
         self._g_buffer, self._g_B, self._g_T = buffer, int(batch_size), int(buffer.episode_limit)
         # static observations in every stored episode (see _forward_backward_full): baked into the captured launches
-        self._g_obs_static = bool(getattr(buffer, "obs_static", False)) and os.environ.get("MACJD_LEARNER_STATIC_OBS", "1") != "0"
+        self._g_obs_static = bool(getattr(buffer, "obs_static", False)) and options.on("LEARNER_STATIC_OBS")
         # the actor rows of each sequence's observation ride in the scan launch's prologue (MACJD_ACTOR_IN_SCAN=0: the
         # actor chain as its own launch on the origin stream)
-        self._g_actor_in_scan = os.environ.get("MACJD_ACTOR_IN_SCAN", "1") != "0"
-        self._g_scan_from_ring = self._g_obs_static and os.environ.get("MACJD_SCAN_FROM_RING", "1") != "0" \
-            and int(buffer.buffers["obs"].shape[-1]) <= 3 * int(self.args.rnn_hidden_dim)
+        self._g_actor_in_scan = options.on("ACTOR_IN_SCAN")
+        self._g_scan_from_ring = self._g_obs_static and int(buffer.buffers["obs"].shape[-1]) <= 3 * int(self.args.rnn_hidden_dim)
         # (a re-capture with the same batch size keeps the index tensor: the batch the last update drew for the next one is
         # still in it, so the sequence of updates continues as if nothing had been re-captured)
         prev_idx = getattr(self, "_g_idx", None)
@@ -604,7 +615,7 @@ class QMixLearner:
         # launch (ops.sample_episodes: uniform without replacement over the stored episodes, like the reference's
         # np.random.choice in buffer.sample): no index upload between two replayed updates — that copy and its two
         # stream-order hops were ~10 us of a ~190 us step.  MACJD_DEVICE_SAMPLER=0: host draw + upload.
-        self._g_dev_sampler = self._flat_param is not None and os.environ.get("MACJD_DEVICE_SAMPLER", "1") != "0"
+        self._g_dev_sampler = self._flat_param is not None and options.on("DEVICE_SAMPLER")
         if not keep_idx:
             self._g_n_stored = torch.zeros(1, dtype=torch.int32, device=self.device)
         if getattr(self, "_g_draws", None) is None:   # draws made so far (the sampler's counter; survives a re-capture)
@@ -630,7 +641,7 @@ class QMixLearner:
         def body_a():
             if fused:
                 pre = (None, None)
-                if self._g_scan_from_ring and os.environ.get("MACJD_UPDATE_STREAMS", "2") != "1":
+                if self._g_scan_from_ring and options.get("UPDATE_STREAMS") != "1":
                     pre = self._scan_from_ring_early()
                 ops.gather_rows(self._g_idx, srcs, [stage[k] for k in keys])
                 return self._forward_backward_full(stage, self._g_T, pre_scan=pre[0], pre_actor=pre[1])
@@ -673,7 +684,7 @@ class QMixLearner:
         # default: no multi-GPU node was available to run it on; only its capture / replay
         # mechanics are tested, with a one-rank RCCL group (tests/test_dist_gpu.py).
         self._g_graphed_ar = bool(graphed_allreduce if graphed_allreduce is not None
-                                  else os.environ.get("MACJD_GRAPHED_ALLREDUCE", "0") == "1") and self._ar_capturable()
+                                  else options.get("GRAPHED_ALLREDUCE") == "1") and self._ar_capturable()
         self._g_single = (self._world_size() <= 1 and not force_two_graphs) or self._g_graphed_ar
         with hipgraph.capture(self._graph_a):
             self._g_out_a = body_a()
@@ -695,7 +706,7 @@ class QMixLearner:
         # K consecutive updates as ONE graph (train_from_buffer_many): between two replayed graphs the stream pays a
         # launch-to-launch hand-over (~20 us here) that an edge inside a graph does not.  Needs the device-side draw (every
         # update's batch comes from the previous update's last launch) and a single process (no all-reduce in between).
-        K = int(updates_per_graph if updates_per_graph is not None else os.environ.get("MACJD_UPDATES_PER_GRAPH", "1"))
+        K = int(updates_per_graph if updates_per_graph is not None else options.get("UPDATES_PER_GRAPH"))
         self._g_multi = None
         if K > 1 and self._g_single and self._g_dev_sampler and fused and self._g_stats4 is not None:
             gm, rows, single_norm = torch.cuda.CUDAGraph(), [], self._grad_norm
@@ -705,8 +716,8 @@ class QMixLearner:
             # serial tail; update k + 1 then starts at its taken-action Q-head and finds the scan done at its join
             # (-17 us per pipelined update: the gather, its hand-over and the wait for the scan leave the chain).  Same
             # launches on the same data in an order that respects every dependence: same results (tested bitwise).
-            pipelined = (self._g_scan_from_ring and self._g_actor_in_scan and os.environ.get("MACJD_UPDATE_STREAMS", "2") != "1"
-                         and os.environ.get("MACJD_PIPELINED_GROUP", "1") != "0")
+            pipelined = (self._g_scan_from_ring and self._g_actor_in_scan and options.get("UPDATE_STREAMS") != "1"
+                         and options.on("PIPELINED_GROUP"))
             stage2 = {k: torch.zeros_like(v) for k, v in stage.items()} if pipelined else None
             stages = [stage, stage2]
             origin_dev = self.device
@@ -760,7 +771,7 @@ class QMixLearner:
             self._g_multi = (K, gm, rows)
             self._g_pipelined = pipelined
         self._g_shared_body = self._body_is_shared()   # baked into the captured launches
-        assert self._g_obs_static == (bool(getattr(buffer, "obs_static", False)) and os.environ.get("MACJD_LEARNER_STATIC_OBS", "1") != "0")
+        assert self._g_obs_static == (bool(getattr(buffer, "obs_static", False)) and options.on("LEARNER_STATIC_OBS"))
         self._graphs_ready = True
 
     def release_graphs(self):

@@ -156,8 +156,9 @@ def save_checkpoint(learner, runner, save_dir, episode, total_steps):
     if draws is not None:   # the device-side episode sampler's counter (core/qmix.py, enable_graphs)
         state["sample_draws"] = int(draws.item())
     ep_idx = getattr(runner.env, "episode_index", None)
-    if ep_idx is not None:
+    if ep_idx is not None:   # every env's episode index (its Monte-Carlo stream position): envs reset under a mask differ
         state["env_episode"] = int(ep_idx.max().item())
+        state["env_episode_index"] = [int(v) for v in ep_idx.cpu().tolist()]
     with open(os.path.join(save_dir, "trainer_state.json"), "w") as f:
         json.dump(state, f)
 
@@ -180,9 +181,18 @@ def load_checkpoint(learner, runner, load_dir):
             runner._ep = int(state["runner_ep"])
         if "sample_rng" in state:
             learner._sample_rng.bit_generator.state = state["sample_rng"]
-        learner._resume_draws = int(state.get("sample_draws", 0))   # applied when enable_graphs creates the counter
-        if "env_episode" in state and getattr(runner.env, "episode_index", None) is not None:
-            runner.env.episode_index.fill_(int(state["env_episode"]))
+        learner._resume_draws = int(state.get("sample_draws", 0))   # applied when enable_graphs creates the counter ...
+        if getattr(learner, "_g_draws", None) is not None:          # ... or right away when it exists already
+            learner._g_draws.fill_(learner._resume_draws)
+        ep_idx = getattr(runner.env, "episode_index", None)
+        if ep_idx is not None and "env_episode_index" in state:
+            vec = np.asarray(state["env_episode_index"], dtype=np.int64)
+            if vec.shape == tuple(ep_idx.shape):
+                ep_idx.copy_(torch.as_tensor(vec).to(ep_idx.dtype))
+            else:   # another batch size than the checkpoint's: every env continues behind the furthest one
+                ep_idx.fill_(int(vec.max()))
+        elif ep_idx is not None and "env_episode" in state:
+            ep_idx.fill_(int(state["env_episode"]))
     return state
 
 
@@ -233,6 +243,12 @@ def run(args):
     batch_envs = int(getattr(args, "batch_envs", 1) or 1)
     episodes_per_run = batch_envs
     use_graphs = bool(getattr(args, "hip_graphs", True)) and args.use_cuda and batch_envs > 1
+    # config/default.yaml is scaled for batch_envs = 4096 (epsilon annealed over 2500 steps PER ENV, 200 M collected steps);
+    # the reference's own protocol (one env) anneals over 100 000 of its 2 M steps (reference config/default.yaml:21-23,60)
+    if batch_envs == 1 and (args.epsilon_anneal_time < 20000 or args.total_env_steps > 20_000_000):
+        print(f"WARNING: batch_envs = 1 with epsilon_anneal_time = {args.epsilon_anneal_time} / total_env_steps = "
+              f"{args.total_env_steps}: these look like the values scaled for thousands of envs; the reference protocol uses "
+              f"epsilon_anneal_time: 100000 and total_env_steps: 2000000")
 
     episode, total_steps = 0, 0
     if getattr(args, "resume", None):

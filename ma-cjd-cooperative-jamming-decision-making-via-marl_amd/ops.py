@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import _native
+from . import _native, options
 
 
 def _stream(t: torch.Tensor) -> int:
@@ -991,10 +991,6 @@ class deferred_wgrad:
         if exc[0] is None and pending:
             lib = _native.load()
             dev = pending[0][1][0].device
-            if os.environ.get("MACJD_WGRAD_DEBUG") == "1":   # the problem list of a flush (shapes, strides, alignment)
-                for io, _ in pending:
-                    print(f"[wgrad] K={io.K} M={io.M} N={io.N} gout_ld={io.gout_ld} (ptr%16={io.gout % 16}) "
-                          f"inp_ld={io.inp_ld} (ptr%16={io.inp % 16}) dw_ld={io.dw_ld} db={'y' if io.db else 'n'}", flush=True)
             for lo in range(0, len(pending), 8):
                 part = pending[lo:lo + 8]
                 arr = (_native.WgradIO * len(part))(*[io for io, _ in part])
@@ -1412,7 +1408,7 @@ class _LinearReluRowDot(torch.autograd.Function):
         x, w1, y, w2 = ctx.saved_tensors
         nd = ctx.needs_input_grad
         gW1 = gb1 = gW2 = gb2 = None
-        if nd[0] or os.environ.get("MACJD_WGRAD_OUTER", "1") == "0":
+        if nd[0] or not options.on("WGRAD_OUTER"):
             g = _splitrelu_backward_launch(y, [y.shape[1]], 0, [gq], None, [w2])   # gq w2 masked by the ReLU, [n, H]
             gx = g.matmul(w1) if nd[0] else None
             if nd[1] or nd[2]:
@@ -1483,7 +1479,7 @@ def qhead_taken_supported(h, w1, w2, n_actions: int) -> bool:
     return (h.is_cuda and h.dim() == 2 and h.dtype == torch.float32 and w1.dtype == torch.float32 and not torch.is_autocast_enabled()
             and h.shape[0] >= 1024 and w1.shape[0] == h.shape[1] and w1.shape[1] == h.shape[1] + n_actions + 1
             and w2.shape[0] == 1 and torch.is_grad_enabled() and (w1.requires_grad or w2.requires_grad) and not h.requires_grad
-            and os.environ.get("MACJD_QHEAD_TAKEN", "1") != "0"
+            and options.on("QHEAD_TAKEN")
             and bool(_native.load().macjd_qhead_taken_supported(int(h.shape[1]), int(n_actions))))
 
 

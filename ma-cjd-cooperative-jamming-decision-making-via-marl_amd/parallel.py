@@ -52,12 +52,13 @@ def broadcast_parameters(modules, src: int = 0) -> None:
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
         return
     for m in modules:
-        params = [p.data for p in m.parameters()]
+        params = list(m.parameters())
         if not params:
             continue
-        flat = torch.cat([p.reshape(-1) for p in params])
+        flat = torch.cat([p.detach().reshape(-1) for p in params])
         dist.broadcast(flat, src=src)
         off = 0
-        for p in params:
-            p.copy_(flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
+        with torch.no_grad():   # (copy_ on the parameter itself, not on .data: its version counter moves, which is what
+            for p in params:    # QMixLearner._body_is_shared watches)
+                p.copy_(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()

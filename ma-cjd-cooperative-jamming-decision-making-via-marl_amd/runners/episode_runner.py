@@ -15,9 +15,13 @@ import os
 from functools import partial
 from typing import Dict
 
+import itertools
+
 import numpy as np
 import torch
 
+
+_ENV_SERIAL = itertools.count(1)   # static-content tags of the replay slots (BatchedEpisodeRunner.end_episodes)
 
 class EpisodeBatch:
     """Per-episode staging arrays (episode_runner.py:184-277)."""
@@ -251,7 +255,9 @@ class BatchedEpisodeRunner:
             tags = None
             if self._static:   # env e's static rows never change: identify them so that unchanged slots are not rewritten
                 if getattr(self, "_static_tags", None) is None:
-                    base = (id(self.env) & 0xFFFFFFFF) << 24
+                    # a process-unique serial per environment object (an object's address can be handed to a later
+                    # environment with another scenario, whose rows must not be mistaken for this one's)
+                    base = next(_ENV_SERIAL) << 24
                     self._static_tags = base + np.arange(self.batch_envs, dtype=np.int64)
                 tags = self._static_tags
             self.buffer.store_episodes_batched(self.stage, self.batch_envs, obs_static=self._static, static_tags=tags)
@@ -330,7 +336,7 @@ class BatchedEpisodeRunner:
         self.t_env += n
 
     # ---- whole-episode launches: the agent's T steps as one kernel, the env's T steps as another ----
-    fused_rollout = os.environ.get("MACJD_FUSED_ROLLOUT", "1") != "0"
+    fused_rollout = True   # class / instance switch (tests set it): whole-episode launches where available
 
     def fused_rollout_available(self) -> bool:
         """The observation is static (so the agent's steps do not depend on the env's outputs), the MAC is the stock

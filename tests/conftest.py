@@ -12,6 +12,41 @@ for p in (REPO, os.path.join(REPO, "tests")):
 import macjd_amd  # noqa: E402,F401  (before the first torch.cuda call: reserves the graph-launch hardware queue, hipgraph.py)
 
 
+def _reload_switches():
+    """The package and the native library read their MACJD_* switches once: re-read after a test changed one."""
+    from macjd_amd import options
+    options.reload()
+    if _has_gpu():
+        from macjd_amd import _native
+        _native.reload_options()
+
+
+_MP = pytest.MonkeyPatch
+_orig_setenv, _orig_delenv, _orig_undo = _MP.setenv, _MP.delenv, _MP.undo
+
+
+def _setenv(self, name, value, prepend=None):
+    _orig_setenv(self, name, value, prepend)
+    if name.startswith("MACJD_"):
+        _reload_switches()
+
+
+def _delenv(self, name, raising=True):
+    _orig_delenv(self, name, raising)
+    if name.startswith("MACJD_"):
+        _reload_switches()
+
+
+def _undo(self):
+    touched = any(isinstance(k, str) and k.startswith("MACJD_") for _, k, _ in getattr(self, "_setitem", []))
+    _orig_undo(self)
+    if touched:
+        _reload_switches()
+
+
+_MP.setenv, _MP.delenv, _MP.undo = _setenv, _delenv, _undo
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -1797,6 +1797,38 @@ def test_updates_grouped_into_one_graph_equal_single_updates():
         assert torch.equal(a, b), k_
 
 
+def test_body_written_through_data_is_noticed_when_graphs_are_captured():
+    """The shared-body bookkeeping watches autograd version counters, which a write through ``p.data`` does not move
+    (polyak-style target updates, hand-written broadcasts): enable_graphs() compares the VALUES of the two controllers'
+    frozen bodies, so such a write ends the sharing at the next capture — and equal values restore it."""
+    from macjd_amd.core.mac import BasicMAC
+    from macjd_amd.core.qmix import QMixLearner
+    from macjd_amd.utils.replay_buffer import EpisodeReplayBuffer
+    from tests_golden_helpers import synthetic_batch
+    g, d = load("3j4r_h64")
+    T, N, B = 100, 40, 32
+    args = _gpu_args(d, episode_limit=T, buffer_size=N, batch_size=B)
+    with quiet():
+        mac = BasicMAC(d["S"], args)
+        mac.load_state(sd_from(g, "g5_agent0."))
+        learner = QMixLearner(mac, args)
+        buf = EpisodeReplayBuffer(args)
+    full = synthetic_batch(np.random.default_rng(3), args, N, T)
+    for kk, v in buf.buffers.items():
+        v.copy_(torch.as_tensor(full[kk]).to(v.dtype))
+    buf.current_size, buf.current_index = N, 0
+    buf.episode_lengths[:] = T
+    assert learner._body_is_shared()
+    learner.target_mac.agent.fc1.weight.data.mul_(1.5)          # invisible to the version counter
+    assert learner._body_is_shared()                             # ... so the cheap check still says "shared"
+    learner.enable_graphs(buf, B)
+    assert not learner._g_shared_body and not learner._body_is_shared()
+    assert np.isfinite(learner.train_from_buffer()["loss"])
+    learner._update_targets()                                    # hard sync: identical again
+    learner.enable_graphs(buf, B)
+    assert learner._g_shared_body
+
+
 def test_learner_graphs_recaptured_and_released_in_one_process():
     """enable_graphs() is meant to be called again mid-run (after the buffer lost its static-observation flag, the agent
     body changed, another grouping is wanted): every call destroys the previous graphs first (QMixLearner.release_graphs:
