@@ -283,15 +283,18 @@ __global__ void __launch_bounds__(256) agent_episode_kernel(const macjd_agent_ep
 
 // ---------------------------------------------------------------------------------------------------------------
 // Double-DQN target values from hidden states (include/macjd_nets.h, macjd_doubleq_io): workgroup = 16 rows; wave w
-// computes the Q-head base columns [16w, 16w+16) of BOTH networks (8 quads of MFMA each), then wave 0 evaluates the eval
-// head and wave 1 the target head for all actions (lane = (row, quarter of the 64 units), as in agent_episode_kernel),
-// the arg-max crosses through 64 bytes of LDS.
+// computes the Q-head base columns [16w, 16w+16) of BOTH networks (8 quads of MFMA each), then all four waves evaluate
+// the heads for all actions — wave w: head (w & 1) (0 = eval, 1 = target), action half (w >> 1), lane = (row, quarter of
+// the 64 units) as in agent_episode_kernel — and the first arg-max of the eval head (its two halves meet through LDS)
+// picks the target head's value.  (Round 2 used two of the four waves for the all-action phase: 156 us at A = 33.)
 template <int A>
 __global__ void __launch_bounds__(256) qhead_double_q_kernel(const macjd_doubleq_io io) {
+    constexpr int AH = (A + 1) / 2;                                      // actions per half (the second half may hold one less)
     __shared__ __attribute__((aligned(16))) float Hs[2][16 * EP_LD];    // h rows of the eval / target unroll
     __shared__ __attribute__((aligned(16))) float Bs[2][16 * EP_LD];    // base of the eval / target head
     __shared__ float Wq[2][(A + 2) * EP_H];
-    __shared__ int amax_s[16];
+    __shared__ float amax_q[2][16];
+    __shared__ int amax_i[2][16];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, g = lane >> 4;
@@ -306,17 +309,18 @@ __global__ void __launch_bounds__(256) qhead_double_q_kernel(const macjd_doubleq
     }
     const int u = 16 * wave + li;
     const float b1e = io.b1_e[u], b1t = io.b1_t[u];
-    // Q-head roles: wave 0 = eval head, wave 1 = target head; lane = (row qr, quarter qq)
+    // all-action roles: head = wave & 1, actions [a0, a0 + na); lane = (row qr, quarter qq)
+    const int head = wave & 1, a0 = (wave >> 1) * AH, na = (wave >> 1) ? A - AH : AH;
     const int qr = lane & 15, qq = lane >> 4;
     const int64_t nq = (n0 + qr < io.n_rows) ? n0 + qr : io.n_rows - 1;
-    float pv[A];
+    float pv[AH];
     {
         const int64_t np = io.p_group > 0 ? (nq / io.p_group) * io.p_inner + nq % io.p_inner : nq;   // one P row per sequence
-        const float* prow = (wave == 1) ? io.P_t + np * io.pt_ld : io.P_e + np * io.pe_ld;
+        const float* prow = head ? io.P_t + np * io.pt_ld : io.P_e + np * io.pe_ld;
 #pragma unroll
-        for (int a = 0; a < A; ++a) pv[a] = prow[a];
+        for (int a = 0; a < AH; ++a) pv[a] = prow[a0 + (a < na ? a : na - 1)];
     }
-    const float b2 = (wave == 1) ? io.b2_t[0] : io.b2_e[0];
+    const float b2 = head ? io.b2_t[0] : io.b2_e[0];
     // h rows -> LDS (float4 pieces when aligned; rows past n: the last row, never stored)
     for (int idx = threadIdx.x; idx < 2 * 16 * (EP_H / 4); idx += 256) {
         const int which = idx / (16 * (EP_H / 4)), rem = idx - which * 16 * (EP_H / 4);
@@ -355,12 +359,12 @@ __global__ void __launch_bounds__(256) qhead_double_q_kernel(const macjd_doubleq
         }
     }
     __syncthreads();
-    float q[A];
-    if (wave < 2) {   // wave-uniform
-        const float* wq = Wq[wave];
+    float q[AH];
+    {
+        const float* wq = Wq[head];
 #pragma unroll
-        for (int a = 0; a < A; ++a) q[a] = 0.0f;
-        const float* brow = &Bs[wave][qr * EP_LD + 16 * qq];
+        for (int a = 0; a < AH; ++a) q[a] = 0.0f;
+        const float* brow = &Bs[head][qr * EP_LD + 16 * qq];
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4) {
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + 4 * k4);
@@ -369,8 +373,8 @@ __global__ void __launch_bounds__(256) qhead_double_q_kernel(const macjd_doubleq
                 const int uu = 16 * qq + 4 * k4 + kk;
                 const float wp = wq[A * EP_H + uu], w2u = wq[(A + 1) * EP_H + uu];
 #pragma unroll
-                for (int a = 0; a < A; ++a) {
-                    float v = b4[kk] + wq[a * EP_H + uu];
+                for (int a = 0; a < AH; ++a) {
+                    float v = b4[kk] + wq[(a0 + (a < na ? a : na - 1)) * EP_H + uu];
                     v = fmaf(pv[a], wp, v);
                     v = fmaxf(v, 0.0f);
                     q[a] = fmaf(v, w2u, q[a]);
@@ -378,27 +382,29 @@ __global__ void __launch_bounds__(256) qhead_double_q_kernel(const macjd_doubleq
             }
         }
 #pragma unroll
-        for (int a = 0; a < A; ++a) {
+        for (int a = 0; a < AH; ++a) {
             q[a] += __shfl_xor(q[a], 16, 64);
             q[a] += __shfl_xor(q[a], 32, 64);
             q[a] += b2;
         }
-        if (wave == 0 && qq == 0) {   // first maximum of the unmasked eval values (qmix.py:138-143)
+        if (head == 0 && qq == 0) {   // first maximum of this half's unmasked eval values (qmix.py:138-143)
             int am = 0;
             float aq = q[0];
 #pragma unroll
-            for (int a = 1; a < A; ++a)
-                if (q[a] > aq) { aq = q[a]; am = a; }
-            amax_s[qr] = am;
-            if (io.argmax_out && n0 + qr < io.n_rows) io.argmax_out[n0 + qr] = am;
+            for (int a = 1; a < AH; ++a)
+                if (a < na && q[a] > aq) { aq = q[a]; am = a; }
+            amax_q[wave >> 1][qr] = aq;
+            amax_i[wave >> 1][qr] = a0 + am;
         }
     }
     __syncthreads();
-    if (wave == 1 && qq == 0 && n0 + qr < io.n_rows) {   // qmix.py:147
-        const int am = amax_s[qr];
+    // the first maximum over both halves: the second half wins only with a strictly larger value
+    const int am = (amax_q[1][qr] > amax_q[0][qr]) ? amax_i[1][qr] : amax_i[0][qr];
+    if (wave == 0 && qq == 0 && io.argmax_out && n0 + qr < io.n_rows) io.argmax_out[n0 + qr] = am;
+    if (head == 1 && qq == 0 && n0 + qr < io.n_rows && am >= a0 && am < a0 + na) {   // qmix.py:147
         float gq = 0.0f;
 #pragma unroll
-        for (int a = 0; a < A; ++a) gq = (a == am) ? q[a] : gq;
+        for (int a = 0; a < AH; ++a) gq = (a0 + a == am) ? q[a] : gq;
         io.out[n0 + qr] = gq;
     }
 }
