@@ -584,7 +584,7 @@ class QMixLearner:
 
     # ------------------------------------------------------------------ HIP-graph path
     def enable_graphs(self, buffer, batch_size, warmup_iters=3, force_two_graphs=False, updates_per_graph=None,
-                      graphed_allreduce=None):
+                      graphed_allreduce=None, prime=True):
         """Capture the update as two HIP graphs around the (eager) gradient all-reduce (ONE graph holding both halves
         when there is a single process, i.e. nothing to all-reduce):
           graph A  gather the sampled episodes from the device replay (static index tensor) + both
@@ -664,16 +664,19 @@ class QMixLearner:
                 body_a()
                 self._clip_and_step()   # (no draw: the warm-up leaves the sampler's counter alone)
         torch.cuda.current_stream(self.device).wait_stream(s)
-        with torch.no_grad():
-            for p, sp in zip(self.params, snap_p):
-                p.copy_(sp)
-            for p, st in self.optimizer.state.items():
-                for k, v in st.items():
-                    if torch.is_tensor(v):
-                        old = snap_o.get(id(p), {}).get(k)
-                        v.copy_(old) if old is not None else v.zero_()
-        if was_shared:
-            self._mark_body_shared()   # the restore wrote the (unchanged) body values back: still identical
+        def restore_training_state():
+            with torch.no_grad():
+                for p, sp in zip(self.params, snap_p):
+                    p.copy_(sp)
+                for p, st in self.optimizer.state.items():
+                    for k, v in st.items():
+                        if torch.is_tensor(v):
+                            old = snap_o.get(id(p), {}).get(k)
+                            v.copy_(old) if old is not None else v.zero_()
+            if was_shared:
+                self._mark_body_shared()   # the restore wrote the (unchanged) body values back: still identical
+
+        restore_training_state()
         self._graph_a, self._graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # a single process has no all-reduce between the two halves: one graph, one launch per update
         # (force_two_graphs: the layout every rank of a multi-GPU job runs, for single-process tests)
@@ -772,6 +775,24 @@ class QMixLearner:
             self._g_pipelined = pipelined
         self._g_shared_body = self._body_is_shared()   # baked into the captured launches
         assert self._g_obs_static == (bool(getattr(buffer, "obs_static", False)) and options.on("LEARNER_STATIC_OBS"))
+        # Prime the graphs: the FIRST launch of an instantiated graph pays one-off costs (its streams get their hardware
+        # queues, kernel arguments are uploaded) that belong to setting up, not to the first update a caller times.  One
+        # replay of each graph on valid indices, then the training state — weights, optimiser moments, the sampler's
+        # counter and drawn batch — goes back to what it was.
+        if prime:
+            keep = (self._g_draws.clone(), self._g_idx.clone(), self._g_n_stored.clone())
+            self._g_n_stored.fill_(int(buffer.current_size))
+            self._g_idx.clamp_(0, max(0, int(buffer.current_size) - 1))
+            hipgraph.replay(self._graph_a, self.device)
+            if not self._g_single:
+                self._allreduce_grads()
+                hipgraph.replay(self._graph_b, self.device)
+            if self._g_multi is not None:
+                self._g_idx.clamp_(0, max(0, int(buffer.current_size) - 1))
+                hipgraph.replay(self._g_multi[1], self.device)
+            torch.cuda.synchronize(self.device)
+            restore_training_state()
+            self._g_draws.copy_(keep[0]); self._g_idx.copy_(keep[1]); self._g_n_stored.copy_(keep[2])
         self._graphs_ready = True
 
     def release_graphs(self):
