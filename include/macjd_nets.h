@@ -448,8 +448,8 @@ int macjd_gru_gates(const macjd_grugates_io* io, void* hip_stream);
  * first layer `gout1` [M, 2 Hh + 2 Em].  No gradient flows to the state.  The weight / bias / LayerNorm-parameter
  * gradients are split-K products of these matrices (macjd_linear_wgrad_many, macjd_layernorm_param_grad).
  *
- * Supported: hyper_hidden_dim Hh = 128, mixing_embed_dim Em = 64 (the reference's sizes), n_agents J in {2, 3, 6},
- * state_dim S <= 16 * {2, 3, 6} resp. (the shipped 2j/2r, 3j/4r and 6j/8r scenarios); everything else returns
+ * Supported: hyper_hidden_dim Hh = 128, mixing_embed_dim Em = 64 (the reference's sizes), n_agents J in {2, 3, 6, 12},
+ * state_dim S <= 16 J (the shipped 2j/2r, 3j/4r, 6j/8r and 12j/16r scenarios; J = 12 runs both layers in passes); everything else returns
  * MACJD_EUNSUPPORTED and the caller keeps the unfused kernels.
  */
 typedef struct macjd_mixerf_io {
@@ -501,7 +501,9 @@ int macjd_mixer_fused_backward_td(const macjd_mixerf_io* io, const macjd_tdloss_
  * environments are independent.  Exact float32 (v_mfma_f32_16x16x4_f32); gate and Q-head expressions and the Philox
  * exploration draws are those of macjd_gru_gates / macjd_qhead_select (same (row, counter) keying), so the episode equals
  * the step-by-step rollout up to the summation order of the two matrix products.
- * Supported: H = 64, J in {2, 3, 6}, A in {5, 9, 17} (MACJD_EUNSUPPORTED otherwise).
+ * Supported: H = 64, A in {5, 9, 17, 33}, any J >= 1 (J in {2, 3, 6} with A <= 17: one row tile per agent as described; every
+ * other size: four tiles of 16 consecutive rows n = env * J + agent per workgroup — the arithmetic per row is the same);
+ * MACJD_EUNSUPPORTED otherwise.
  */
 typedef struct macjd_agent_episode_io {
     int64_t n_envs;            /* E */
