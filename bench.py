@@ -336,9 +336,9 @@ def main():
                 "timing": "HIP events around 50 launches replayed from one HIP graph on their own stream (macjd_env_step_many_timed); "
                           "the committed rocprofv3 kernel-trace summary of this launch alone is quoted under 'profile'",
                 "traffic_measured_in_run": False,
-                "limiter": "VALU issue, not HBM: ~780 VALU instructions per env-step at 3j/4r (~190 float64 for the power / SNR "
-                           "quotients, 2 Philox blocks = 55 quarter-rate 32 x 32 multiplies, 7 float32 detection probabilities "
-                           "with a float64 fallback for compares within 2e-6) for 41 bytes; traffic = 1.01x algorithmic (DESIGN.md 4.1)",
+                "limiter": "VALU issue, not HBM: ~735 VALU instructions per env-step at 3j/4r (~145 float64 for the power / received-power "
+                           "quotients, 2 Philox blocks = 40 quarter-rate 32 x 32 multiplies, float32 SNR / detection probabilities "
+                           "with a float64 fallback for compares within 4e-6) for 41 bytes; traffic = 1.01x algorithmic (DESIGN.md 4.1)",
                 "bytes_per_env_step": round(B_many, 2), "env_steps_per_launch": Tn * E,
                 "single_step_launch": single}
     prof_m = profiled_kernel_time("env_step_kernel<", args.per_env, pattern=f"r*_env_many_step_{J}j{R}r_kernel_stats.csv")

@@ -160,21 +160,23 @@ __device__ __forceinline__ double det_prob(double snr, const PdConsts& k) {
 // PD32 (production variant on regular scenarios): the detection probability in float32 on the transcendental unit —
 // pd = 1 / (1 + 2^y), y = -log2(e) B = ky1 snr + ky0 (one fma, v_exp_f32, v_add, v_rcp_f32: 5 instructions instead of ~60
 // float64 ones incl. a 13-term exp polynomial and two refined reciprocals) — used where a value within 1e-5 is all the
-// consumer needs (the reward terms), and as a FILTER for the Monte-Carlo compares u <= pd: with |pd32 - pd| <= 4e-7
-// (argument rounding (|y| + |ky0|) 1.8e-7 times |dpd/dy| <= 0.173 pd (1 - pd) -> <= 1e-7; v_exp_f32 and v_rcp_f32 1 ulp each,
-// the add's rounding: <= 3e-7 together) and the float32 image of u within 1.2e-7, a compare whose two sides differ by more
-// than PD32_BOUND = 2e-6 has the same outcome in float64; the others (~4e-6 of all compares) evaluate the exact float64
-// chain.  FSM bits, hit decisions and therefore every integer output are those of the float64 kernel bit for bit; reward
-// terms differ from it by <= (R + J) 4e-7 (tested: bitwise-equal track / terminated, rewards within 1e-5, on the 70 000-env
+// consumer needs (the reward terms), and as a FILTER for the Monte-Carlo compares u <= pd.  The radars' SNR itself is a
+// float32 quotient there (GaPs * v_rcp_f32(D supp + Pn), the sum still formed in float64): relative error <= 3.5e-7, i.e.
+// |dy| <= |ky1| snr 3.5e-7 + (|y| + |ky0|) 1.8e-7 (the fma and the two constants); |dpd/dy| <= 0.173 pd (1 - pd), which is
+// < 1e-3 wherever snr > 3 (B > 4.9): |dpd| <= 3e-7 from the argument; v_exp_f32 and v_rcp_f32 1 ulp each and the add's
+// rounding add <= 3e-7: **|pd32 - pd| <= 6e-7**; the float32 image of u is within 1.2e-7.  A compare whose two sides differ
+// by more than PD32_BOUND = 4e-6 therefore has the same outcome in float64; the others (~8e-6 of all compares) evaluate
+// the exact float64 chain, SNR included.  FSM bits, hit decisions and therefore every integer output are those of the float64 kernel bit for bit; reward
+// terms differ from it by <= (R + J) 6e-7 (tested: bitwise-equal track / terminated, rewards within 1e-5, on the 70 000-env
 // edge batch).  MACJD_ENV_PD32=0 selects the all-float64 form.
-constexpr float PD32_BOUND = 2e-6f;
+constexpr float PD32_BOUND = 4e-6f;
 struct Pd32Consts { float ky1, ky0; };
 __device__ __forceinline__ Pd32Consts pd32_consts(double A, double c1, double denB) {
     const double l2e = 1.4426950408889634;
     return Pd32Consts{(float)(-l2e * 10.0 / denB), (float)(-l2e * (10.0 * c1 - A) / denB)};
 }
-__device__ __forceinline__ float det_prob32(double snr, const Pd32Consts& k) {
-    const float y = __builtin_fmaf((float)snr, k.ky1, k.ky0);
+__device__ __forceinline__ float det_prob32(float snr, const Pd32Consts& k) {
+    const float y = __builtin_fmaf(snr, k.ky1, k.ky0);
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y));
 }
 
@@ -296,20 +298,17 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
     const int32_t episode_limit = tb->episode_limit;
     const bool arith32 = FAST ? true : ((io.P32 != nullptr) && !(io.flags & MACJD_STEP_ARITH_F64));
 
-    auto env_step_one = [&](const int64_t e_item) {
-        // many-step launches (production variant only, macjd_env_step_many): work item -> (step t, env e);
-        // single-step launches: item = env, t = 0
-        int64_t e = e_item;
-        int32_t tt = 0;
+    auto env_step_one = [&](const int64_t e, const int32_t tt) {
+        // many-step launches (production variant only, macjd_env_step_many): work item (step tt, env e), outputs of the
+        // item at index tt * n_envs + e (the step is wave-uniform: a scalar multiply); single-step launches: tt = 0
         bool many = false, last_t = true;
         if constexpr (FAST) {
             if (io.many_T > 0) {   // grid = (envs / 256, steps): no division
                 many = true;
-                tt = (int32_t)blockIdx.y;
-                e = e_item - (int64_t)tt * io.n_envs;
                 last_t = (tt == io.many_T - 1);
             }
         }
+        const int64_t e_item = FAST ? (int64_t)((uint32_t)tt * (uint32_t)io.n_envs + (uint32_t)e) : e;
         int64_t act_extra = 0;   // element offset of step t's actions
         if constexpr (FAST) act_extra = (int64_t)tt * io.t_stride;
         // Element (env e, item k) of a caller-strided array.  Production variant: the BYTE offset is formed in 32 bits
@@ -536,12 +535,16 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
 
         // ---- SNR with jamming, environment.py:316-333 ----
         double snr_w[NR];
+        float snr32r[PD32 ? NR : 1];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             if (!RT && r >= R) break;
             const double Pn = t_Pn(r);
             const double den = t_D(r) * (SCAT ? s_supp[r][col] : supp[r]) + Pn;   // :331
-            if (REG) {                                                       // den >= Pn > 1e-18
+            if (PD32) {                                                      // float32 quotient (see det_prob32)
+                snr32r[PD32 ? r : 0] = (float)t_GaPs(r) * __builtin_amdgcn_rcpf((float)den);
+                snr_w[r] = 0.0;   // (not formed; the outputs below take the float32 value)
+            } else if (REG) {                                                // den >= Pn > 1e-18
                 snr_w[r] = div_by_refined(t_GaPs(r), den, rcp_refined(den));
                 snr_all[r] = snr_w[r];
             } else if (PRE) {
@@ -576,7 +579,7 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
             uint32_t close_bits = 0;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                const float p32 = det_prob32(snr_all[i], pdk32);
+                const float p32 = det_prob32(i < NR ? snr32r[PD32 && i < NR ? i : 0] : (float)snr_all[i], pdk32);
                 pd32f[i] = p32;
                 const float d = __builtin_fmaf((float)w_all[i], 0x1p-32f, 0x1p-33f) - p32;
                 const bool need = (i < NR) || (dec_tgt[i < NR ? 0 : i - NR] >= 0);
@@ -587,12 +590,16 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
 #pragma unroll 1
                 for (int i = 0; i < NP; ++i) {
                     if (!((close_bits >> i) & 1u)) continue;
-                    double snr_i = snr_all[0];
+                    double snr_i = snr_all[NR];
                     uint32_t w_i = w_all[0];
 #pragma unroll
                     for (int k = 1; k < NP; ++k) {
-                        snr_i = (i == k) ? snr_all[k] : snr_i;
+                        if (k > NR) snr_i = (i == k) ? snr_all[k] : snr_i;
                         w_i = (i == k) ? w_all[k] : w_i;
+                    }
+                    if (i < NR) {   // a radar: the exact SNR from the suppression sum (still in this lane's LDS column)
+                        const double den_i = tb->D[i] * s_supp[SCAT ? i : 0][col] + tb->Pn[i];
+                        snr_i = div_by_refined(tb->GaPs[i], den_i, rcp_refined(den_i));
                     }
                     double p;
                     det_prob_batch_regular<1>(&snr_i, &p, pdk);
@@ -664,7 +671,8 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             if (!RT && r >= R) break;
-            const double snr_rep = (REG || snr_w[r] > 0.0) ? snr_w[r] : 0.0;  // :333 (regular: never negative)
+            const double snr_rep = PD32 ? (double)snr32r[PD32 ? r : 0]
+                                        : ((REG || snr_w[r] > 0.0) ? snr_w[r] : 0.0);  // :333 (regular: never negative)
             if (last_t) at(io.track, e, io.k_se, r, io.k_sx) = (track_bits >> r) & 1u;
             if (io.pd) at(io.pd, e, io.pd_se, r, io.pd_sx) = (float)pd_r[r];
             if (io.snr_with) at(io.snr_with, e, io.sw_se, r, io.sw_sx) = (float)snr_rep;
@@ -697,12 +705,12 @@ __global__ void __launch_bounds__(256) env_step_kernel(const DevTables* __restri
     if constexpr (FAST) {
         // one env per lane, no grid-stride loop: inside a loop every argument and table constant is loop-invariant,
         // gets hoisted and stays live for the whole body (SGPR spills); straight-line code loads them where used
-        const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        if (env < io.n_envs) env_step_one(env + (int64_t)blockIdx.y * io.n_envs);   // (blockIdx.y = step of a many-step launch)
+        const uint32_t env = blockIdx.x * blockDim.x + threadIdx.x;   // (the host checks that every offset fits 32 bits)
+        if ((int64_t)env < io.n_envs) env_step_one((int64_t)env, (int32_t)blockIdx.y);   // (blockIdx.y = step of a many-step launch)
     } else {
         for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < io.n_envs;
              e += (int64_t)gridDim.x * blockDim.x)
-            env_step_one(e);
+            env_step_one(e, 0);
     }
 }
 

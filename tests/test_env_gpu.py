@@ -258,7 +258,7 @@ def test_every_episode_draws_fresh_monte_carlo_values():
 @pytest.mark.parametrize("name,E,n", [("3j4r", 777, 23), ("6j8r", 300, 7), ("2j2r_shipped", 64, 100)])
 def test_many_step_launch_equals_step_by_step(name, E, n, pd32, monkeypatch):
     """(pd32: the many-step launch's float32 detection-probability filter, the default — integer outputs and everything
-    derived from them alone stay bit for bit, the reward's probability terms move by <= (R + J) 4e-7; off: all float64,
+    derived from them alone stay bit for bit, the reward's probability terms move by <= (R + J) 6e-7; off: all float64,
     every output bit for bit.)  macjd_env_step_many: the n steps of an episode batch as ONE launch over n x E independent work items (the FSM's
     next state does not depend on the previous one, core/radar.py:102-117, so given the actions of all steps the env-steps
     are independent) == n single-step launches, bit for bit: rewards, terminated, (r_d, r_p, r_j) per step and summed,
@@ -291,7 +291,7 @@ def test_many_step_launch_equals_step_by_step(name, E, n, pd32, monkeypatch):
         many.step_many(Td.view(n, E, J, 1), Pd.view(n, E, J, 1), rewn, tern, rdn, rdpj_sum=sumn)
         assert torch.equal(tern.view(n, E).to(torch.uint8), ter1)
         if pd32:
-            tol = (R + J) * 4e-7 + 1e-7
+            tol = (R + J) * 6e-7 + 1e-7
             assert torch.equal(rdn[..., :2], rd1[..., :2])                       # r_d (FSM bits), r_p: no probability value
             assert float((rdn[..., 2] - rd1[..., 2]).abs().max()) <= tol and float((rewn.view(n, E) - rew1).abs().max()) <= tol
             assert float((sumn - sum1).abs().max()) <= n * tol
@@ -570,8 +570,10 @@ def test_regular_scenario_variant_equals_ieee_division_variant(name, monkeypatch
         # the float32 filter: every integer output and everything that depends on them alone bit for bit; the reward's
         # probability terms within the stated bound
         assert torch.equal(t0, t1) and torch.equal(i0["radar_tracking"], i1["radar_tracking"]), t
-        for k in ("r_d", "r_p", "snr_with_jamming"):
+        for k in ("r_d", "r_p"):
             assert same(i0[k], i1[k]), (t, k)
+        # (the radars' SNR is a float32 quotient in the filter variant: 3.5e-7 relative)
+        np.testing.assert_allclose(i0["snr_with_jamming"].cpu().numpy(), i1["snr_with_jamming"].cpu().numpy(), rtol=2e-6, atol=0)
         fin = torch.isfinite(r1)
         assert torch.equal(torch.isfinite(r0), fin)
         for a_, b_ in ((r0, r1), (i0["r_j"], i1["r_j"])):
@@ -582,4 +584,4 @@ def test_regular_scenario_variant_equals_ieee_division_variant(name, monkeypatch
         np.testing.assert_allclose(r1[:4096].cpu().numpy(), o["reward"], rtol=0, atol=1e-5)
         np.testing.assert_array_equal(i1["radar_tracking"][:4096].cpu().numpy(), o["track"])
         np.testing.assert_allclose(r0[:4096].cpu().numpy(), o["reward"], rtol=0, atol=1e-5)
-    assert worst <= (R + J) * 4e-7 + 1e-7, worst          # (float32 outputs: + half an ulp of the reward)
+    assert worst <= (R + J) * 6e-7 + 1e-7, worst          # (float32 outputs: + half an ulp of the reward)
