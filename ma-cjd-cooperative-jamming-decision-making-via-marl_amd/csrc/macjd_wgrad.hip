@@ -154,14 +154,35 @@ __device__ __forceinline__ void wgrad_partial_body(const WgradProb& io, const in
     for (int piece = 0; piece < n_pieces; ++piece) {
         const bool more = piece + 1 < n_pieces;
         if (more) load_piece(piece + 1);       // in flight during the products below
-#pragma unroll 8
-        for (int kk = 0; kk < ((MACJD_WG_ABLATE & 1) ? 1 : WG_KC / 4); ++kk) {
-            const float a0 = pa[kk * 4 * WG_PITCH], a1 = pa[kk * 4 * WG_PITCH + 16];
-            const float b0 = pb[kk * 4 * WG_PITCH], b1 = pb[kk * 4 * WG_PITCH + 16];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+        // Two fragment sets, ping-ponged and PINNED (as in macjd_mlp.hip): the four ds_reads of k-step kk + 1 are issued
+        // right behind the first MFMA of k-step kk and consumed one step later, so their LDS latency hides behind three
+        // MFMAs of 32 cycles.  Left alone the scheduler sinks every read next to its use: read -> lgkmcnt(0) -> 4 MFMA per
+        // k-step, which ran the loop at a third of the MFMA rate (PMC, round 3, profiles/r03_wgrad_pmc.txt:
+        // SQ_VALU_MFMA_BUSY_CYCLES = 4 096 per wave = the ideal 128 x 32, but 12 900 cycles of issue stall per wave).
+        constexpr int KSTEPS = (MACJD_WG_ABLATE & 1) ? 2 : WG_KC / 4;
+        float fa0 = pa[0], fa1 = pa[16], fb0 = pb[0], fb1 = pb[16];
+        float ga0, ga1, gb0, gb1;
+#pragma unroll 4
+        for (int kk = 0; kk < KSTEPS; kk += 2) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0, fb0, acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            ga0 = pa[(kk + 1) * 4 * WG_PITCH]; ga1 = pa[(kk + 1) * 4 * WG_PITCH + 16];
+            gb0 = pb[(kk + 1) * 4 * WG_PITCH]; gb1 = pb[(kk + 1) * 4 * WG_PITCH + 16];
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0, fb1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1, fb0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1, fb1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga0, gb0, acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const int kn = (kk + 2 < KSTEPS) ? kk + 2 : KSTEPS - 1;   // past the end: re-read (unused)
+            fa0 = pa[kn * 4 * WG_PITCH]; fa1 = pa[kn * 4 * WG_PITCH + 16];
+            fb0 = pb[kn * 4 * WG_PITCH]; fb1 = pb[kn * 4 * WG_PITCH + 16];
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga0, gb1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga1, gb0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga1, gb1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // bias partial: column sums of the staged gout piece (N-tile 0 only), pieces added in order
         if (bias_lane) {
