@@ -85,6 +85,7 @@ def _make_step_fn(cli, runner, learner, buf, args, T, mode, use_graphs, tails):
 
 
 def make_step(cli, sc, env, dev, rank, world, mode):
+    from . import hipgraph
     from .core.mac import BasicMAC
     from .core.qmix import QMixLearner
     from .runners.episode_runner import BatchedEpisodeRunner
@@ -132,6 +133,8 @@ def make_step(cli, sc, env, dev, rank, world, mode):
              "train_calls_per_step": 1 if mode == "train" else 0,
              "updates_per_graph": (learner._g_multi[0] if (mode == "train" and use_graphs and learner._g_multi) else 1),
              "hip_graphs": bool(use_graphs), "gemm_tuning": bool(gemm_tuning),
+             "graph_launch": {"stream": hipgraph.launch_mode(), "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+                              "allreduce_in_graph": bool(getattr(learner, "_g_graphed_ar", False))},
              "replay_capacity_episodes": args.buffer_size, "mixer_dtype": args.mixer_dtype,
              "mixer": ("one MFMA launch per direction (f32)" if (mode == "train" and learner.eval_qmix_net.fused_available(next(learner.eval_qmix_net.parameters())))
                        else ("library GEMMs (%s) + tail kernel" % args.mixer_dtype)) if mode == "train" else None,
