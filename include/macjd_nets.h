@@ -154,7 +154,8 @@ typedef struct macjd_tdloss_io {
     const uint8_t* terminated; int64_t t_sb, t_st;
     const uint8_t* filled;     int64_t f_sb, f_st;
     float* stats;              /* [4] out: loss, mean(y), mean(target), sum(filled) */
-    float* gy;                 /* out: dL/dy, element (b, t) at gy[b * gy_sb + t] */
+    float* gy;                 /* out: dL/dy, element (b, t) at gy[b * gy_sb + t]; NULL: the logged sums only — stats[0..2]
+                                  are written, stats[3] is left alone, no gradient (macjd_mixer_fused_backward_td forms it) */
 } macjd_tdloss_io;
 
 int macjd_td_loss(const macjd_tdloss_io* io, void* hip_stream);
@@ -478,6 +479,10 @@ typedef struct macjd_mixerf_io {
 
 int macjd_mixer_fused_supported(int32_t J, int32_t S, int32_t Hh, int32_t Em);   /* 1 / 0 */
 int macjd_mixer_fused_forward(const macjd_mixerf_io* io, void* hip_stream);
+/* The eval and the target mixer of one learner update (reference core/qmix.py:151 and :187: the same module class on
+ * two parameter sets and two Q inputs, same states) as ONE grid: `saved` (save = 1: the eval mixer, whose activations the
+ * backward needs) and `plain` (save = 0) must agree in J / S / M.  Results equal the two single launches bit for bit. */
+int macjd_mixer_fused_forward_pair(const macjd_mixerf_io* saved, const macjd_mixerf_io* plain, void* hip_stream);
 int macjd_mixer_fused_backward(const macjd_mixerf_io* io, void* hip_stream);
 /* macjd_mixer_fused_backward that forms dL/dy itself from the TD loss's inputs (macjd_td_loss's expression; td->y = this
    mixer's forward output, td->tq the target values, rows = td->B x td->gy_cols) and tot_m[0] = the batch's mask sum
@@ -554,6 +559,10 @@ typedef struct macjd_doubleq_io {
 
 int macjd_qhead_double_q_supported(int32_t H, int32_t A);
 int macjd_qhead_double_q(const macjd_doubleq_io* io, void* hip_stream);
+/* macjd_qhead_taken and macjd_qhead_double_q of one learner update (reference core/qmix.py:138-147 and :161-184: both read
+ * the same unrolled hidden states, neither reads the other's result) as ONE grid; same A in both.  Results equal the two
+ * single launches bit for bit. */
+int macjd_qheads_pair(const macjd_qtaken_io* taken, const macjd_doubleq_io* dq, void* hip_stream);
 
 #ifdef __cplusplus
 }

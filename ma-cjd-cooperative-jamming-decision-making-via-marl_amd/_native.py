@@ -29,6 +29,7 @@ EXPORTS = [
     "macjd_mixer_fused_supported", "macjd_mixer_fused_forward", "macjd_mixer_fused_backward", "macjd_mixer_fused_backward_td", "macjd_td_mask_sum",
     "macjd_agent_episode_supported", "macjd_agent_episode", "macjd_env_step_many", "macjd_env_step_many_timed",
     "macjd_qhead_double_q_supported", "macjd_qhead_double_q", "macjd_qhead_taken_supported", "macjd_qhead_taken",
+    "macjd_qheads_pair", "macjd_mixer_fused_forward_pair",
 ]
 
 
@@ -354,6 +355,10 @@ def load() -> ctypes.CDLL:
     lib.macjd_qhead_taken_supported.argtypes = [ctypes.c_int32, ctypes.c_int32]
     lib.macjd_qhead_taken.restype = ctypes.c_int
     lib.macjd_qhead_taken.argtypes = [ctypes.POINTER(QtakenIO), ctypes.c_void_p]
+    lib.macjd_qheads_pair.restype = ctypes.c_int
+    lib.macjd_qheads_pair.argtypes = [ctypes.POINTER(QtakenIO), ctypes.POINTER(DoubleQIO), ctypes.c_void_p]
+    lib.macjd_mixer_fused_forward_pair.restype = ctypes.c_int
+    lib.macjd_mixer_fused_forward_pair.argtypes = [ctypes.POINTER(MixerFusedIO), ctypes.POINTER(MixerFusedIO), ctypes.c_void_p]
     lib.macjd_qhead_input.restype = ctypes.c_int
     lib.macjd_qhead_input.argtypes = [ctypes.POINTER(QinputIO), ctypes.c_void_p]
     lib.macjd_layernorm_forward.restype = ctypes.c_int

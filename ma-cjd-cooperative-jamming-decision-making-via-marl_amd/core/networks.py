@@ -313,6 +313,20 @@ class QMixer(nn.Module):
         params = ops._mixerf_params(ln.weight, ln.bias, ln.eps, w_cat_b[0], w_cat_b[1], *l2)
         return ops.mixer_fused_forward(q, s, params, save=False)[0]
 
+    def forward_paired_with_next_fused(self, agent_qs, states):
+        """No-grad forward whose launch rides in the NEXT differentiable fused-mixer forward (another QMixer of the same
+        shape on the same number of rows — the learner's eval mixer): ``ops.pair_mixer_forward_with_next_fused``.  Callers
+        check ``fused_available``.  The returned Q_tot is valid once that forward has run."""
+        q = agent_qs.reshape(-1, self.n_agents)
+        s = states.reshape(-1, self.state_dim)
+        ln, w_cat_b = self.state_norm, self._first_layer_cat()
+        params = ops._mixerf_params(ln.weight, ln.bias, ln.eps, w_cat_b[0], w_cat_b[1], self.hyper_w_1[2].weight,
+                                    self.hyper_w_1[2].bias, self.hyper_w_final[2].weight, self.hyper_w_final[2].bias,
+                                    self.V[2].weight, self.V[2].bias)
+        y = ops.pair_mixer_forward_with_next_fused(q, s, params)
+        q_tot = y.view(agent_qs.size(0), -1, 1)
+        return q_tot.squeeze(1) if q_tot.shape[1] == 1 else q_tot
+
     def forward(self, agent_qs, states, hyper=None):
         """Q_tot = ELU(q . clamp(W1(s),0,5) + clamp(b1(s),-5,5)) . clamp(Wf(s),0,5) + clamp(V(s),-5,5)
         on the LayerNorm-ed state (networks.py:250-315; note clamp, not abs).  Output shape follows

@@ -398,15 +398,15 @@ class QMixLearner:
             return [F.linear(h.reshape(n, H), hd[0][:, :H], m.agent.fc2_q_head[0].bias)
                     for m, h, hd in zip(macs, h_alls, heads)]
 
-        def double_q(bases, params):
+        def double_q(bases, params, paired=False):
             # a* = argmax_a Q_eval (no mask, qmix.py:138-143), Q_target(a*) (qmix.py:147), [B,T+1,J]: one launch from the
             # hidden states, or two Q-head launches on library-GEMM bases
             if fused_dq:
                 hd4 = [(hd[0], m.agent.fc2_q_head[0].bias, hd[1], hd[2]) for m, hd in zip(macs, heads)]
                 # P per sequence [B, J, A] (static observation): row n = (b, t, j) reads P[b, j]
                 pmap = (T1 * J, J) if (pre_actor is not None and params[1].shape[0] != n) else None
-                return ops.qhead_double_q_from_h(bases[1], params[1], hd4[1], bases[0], params[0], hd4[0], H, A,
-                                                 p_row_map=pmap).view(B, T1, J)
+                launch = ops.pair_double_q_with_next_taken if paired else ops.qhead_double_q_from_h
+                return launch(bases[1], params[1], hd4[1], bases[0], params[0], hd4[0], H, A, p_row_map=pmap).view(B, T1, J)
             return ops.qhead_double_q(bases[1], params[1], heads[1], bases[0], params[0], heads[0], H, A).view(B, T1, J)
 
         def eval_forward():
@@ -422,7 +422,47 @@ class QMixLearner:
         # of behind it; the two meet at the TD loss.  (-22 us of a 147 us update.)
         target_beside_head = (two_streams and prefetched is not None and fused_dq and pre_actor is not None
                               and self.target_qmix_net.fused_available(st["state"]))
-        if target_beside_head:
+        # ... or, better, not beside it but INSIDE its launches: both Q-head launches as one grid and both mixers as one
+        # grid on this stream (ops.pair_*): the chain no longer crosses hardware queues to meet the target branch, and
+        # stays on one queue from the previous Adam to this one.
+        paired_heads = (target_beside_head and options.on("PAIRED_HEADS") and self.eval_qmix_net.fused_available(st["state"])
+                        and ops.qhead_taken_supported(st["hidden_state"].view(n, H), heads[1][0], heads[1][1], A))
+        if paired_heads:
+            origin = torch.cuda.current_stream(dev)
+            # The NEXT update's draw / gather / scan runs beside this whole update: it forks HERE (the other staging set's
+            # last readers — the previous update — are done), but its launches are captured behind this update's backward
+            # (_finish_update): the graph runtime keeps a node on its predecessor's hardware queue only if it is that
+            # predecessor's FIRST captured dependent, and every queue change on the chain costs ~10 us.
+            # The same for the PREVIOUS update's logged loss sums (they feed nothing: launched behind this fork, any time
+            # before the group ends).  The chain then meets the side stream exactly twice per update: this fork and the
+            # wait for the prefetched scan right below it.
+            fork_here = torch.cuda.Event()
+            fork_here.record(origin)
+            owed = self._take_owed_loss_sums()
+
+            def side_work():
+                self._launch_loss_sums(owed, fork_here)
+                if after_join is not None:
+                    after_join(fork_here)
+
+            origin.wait_event(prefetched[1])     # the prefetched scan (hence the gather before it on that stream) is there
+            with torch.no_grad():
+                bases = scan_chain()
+                p_eval = pre_actor[1]
+                params = [p_eval if shared else pre_actor[0], p_eval]
+                for t_ in list(bases) + [p for p in params if p is not None]:
+                    t_.record_stream(origin)
+                tq_agents = double_q(bases, params, paired=True)                                # launched with the next call
+            q_taken = self.mac.agent.get_q_value_for_action(
+                st["hidden_state"].view(n, H), st["actions_discrete"].view(n, 1), st["actions_continuous"].view(n, 1),
+                validate=False).view(B, T1, J)                                                  # qmix.py:138-147, 161-184
+            with torch.no_grad():
+                target_q_tot = self.target_qmix_net.forward_paired_with_next_fused(tq_agents, st["state"])
+            eval_q_tot = self.eval_qmix_net(q_taken, st["state"])                               # qmix.py:151, 187
+            ops.assert_pairs_launched()
+            return self._finish_update(st, T, eval_q_tot, target_q_tot, tot_m=prefetched[2] if len(prefetched) > 2 else None,
+                                       side_work=side_work)
+        elif target_beside_head:
             origin = torch.cuda.current_stream(dev)
             ts = self._target_stream
             ts.wait_stream(origin)           # (fork) the previous update's Adam has written the Q-head this branch reads
@@ -494,7 +534,27 @@ class QMixLearner:
             eval_q_tot = eval_forward()
         return self._finish_update(st, T, eval_q_tot, target_q_tot)
 
-    def _finish_update(self, st, T, eval_q_tot, target_q_tot, tot_m=None):
+    def _take_owed_loss_sums(self):
+        owed, self._owed_loss_sums = getattr(self, "_owed_loss_sums", None), None
+        return owed
+
+    def _launch_loss_sums(self, owed, fork=None):
+        """The logged-sums launch of an earlier update (see the paired branch of _forward_backward_full) on the side
+        stream, behind ``fork`` (an event of the origin stream; None: behind everything issued on it so far)."""
+        if owed is None:
+            return
+        row, y, tq, st, T = owed
+        ts = self._target_stream
+        if fork is None:
+            ts.wait_stream(torch.cuda.current_stream(y.device))
+        else:
+            ts.wait_event(fork)
+        with torch.cuda.stream(ts):
+            ops.td_loss_sums_into(row, y, tq, st["reward"], st["terminated"], st["filled"], self.args.gamma, T - 1, 1)
+        for t_ in (row, y, tq):
+            t_.record_stream(ts)
+
+    def _finish_update(self, st, T, eval_q_tot, target_q_tot, tot_m=None, side_work=None):
         # loss over eval steps 0..T-2 against targets built from target steps 1..T-1 (qmix.py:155,190-194)
         for p in self.params:
             p.grad = None
@@ -502,7 +562,7 @@ class QMixLearner:
             # the loss kernel also produces dL/dQ_tot: it seeds the backward pass directly (no ones-fill / multiply).
             # (Measured and dropped: the loss inside the eval mixer's backward launch — its loads and reductions in front of
             # the kernel's chain cost the 7 us the separate launch does: 26.2 vs 7.5 + 17.8 us.)
-            stats_done = None
+            stats_done = stats_branch = None
             if tot_m is not None and ops.fused_mixer_backward_will_run(eval_q_tot):
                 # pipelined update: the batch's mask sum was computed behind its gather, so the eval mixer's backward
                 # launch forms dL/dQ_tot itself (5 loads per row) and the loss launch leaves the serial chain: it still runs
@@ -511,13 +571,28 @@ class QMixLearner:
                 origin = torch.cuda.current_stream(eval_q_tot.device)
                 ts = self._target_stream
                 head_done = torch.cuda.Event()
-                head_done.record(origin)
-                with torch.cuda.stream(ts):
-                    ts.wait_event(head_done)
-                    loss, eval_mean, target_mean, _, self._last_stats4 = ops.td_loss_and_grad(
-                        eval_q_tot, target_q_tot, st["reward"], st["terminated"], st["filled"], self.args.gamma, T - 1, 1)
-                    stats_done = torch.cuda.Event()
-                    stats_done.record(ts)
+                if side_work is None:
+                    head_done.record(origin)
+
+                def stats_branch():
+                    with torch.cuda.stream(ts):
+                        ts.wait_event(head_done)
+                        out = ops.td_loss_and_grad(eval_q_tot, target_q_tot, st["reward"], st["terminated"], st["filled"],
+                                                   self.args.gamma, T - 1, 1)
+                        done = torch.cuda.Event()
+                        done.record(ts)
+                    return out, done
+
+                if side_work is None:
+                    (loss, eval_mean, target_mean, _, self._last_stats4), stats_done = stats_branch()
+                else:
+                    # paired update: the row exists now (the optimiser writes the gradient norm into [3]); its first three
+                    # entries come from a launch that the NEXT update (or the end of the group) issues
+                    row = torch.empty(4, dtype=torch.float32, device=eval_q_tot.device)
+                    self._last_stats4 = row
+                    assert getattr(self, "_owed_loss_sums", None) is None
+                    self._owed_loss_sums = (row, eval_q_tot.detach(), target_q_tot.detach(), st, T)
+                    loss, eval_mean, target_mean = row[0], row[1], row[2]
                 gy = ops.td_grad_in_mixer_backward(eval_q_tot, target_q_tot, st["reward"], st["terminated"], st["filled"],
                                                    self.args.gamma, T - 1, 1, tot_m)
             else:
@@ -531,6 +606,10 @@ class QMixLearner:
                 eval_q_tot.backward(gy)
             assert ops._PENDING_TD is None, "the fused mixer's backward did not take the TD loss's inputs"
             self._held_ln = dw.held
+            if side_work is not None:
+                # side-stream launches whose forks lie earlier (side_work: its own fork; the logged sums: head_done),
+                # captured behind the chain's launches so that the chain's nodes stay first dependents of each other
+                side_work()
             if stats_done is not None:
                 torch.cuda.current_stream(eval_q_tot.device).wait_event(stats_done)
                 for t_ in (self._last_stats4,):
@@ -729,7 +808,9 @@ class QMixLearner:
                 """draw + gather + scan of the NEXT update on the side stream (called behind the current join)"""
                 origin = torch.cuda.current_stream(origin_dev)
                 ts = self._target_stream
-                if fork:
+                if isinstance(fork, torch.cuda.Event):
+                    ts.wait_event(fork)     # (fork recorded earlier on the origin stream)
+                elif fork:
                     ts.wait_stream(origin)  # (fork off the origin stream) the previous users of idx / dst are done
                 shared = self._body_is_shared()
                 agents = [self.mac.agent] if shared else [self.target_mac.agent, self.mac.agent]
@@ -769,6 +850,7 @@ class QMixLearner:
                     # the update's last launch draws the next batch — unless the prefetch behind the join has done so
                     self._clip_and_step(sample_next=None if nxt_batch is not None else nxt)
                 if pipelined:
+                    self._launch_loss_sums(self._take_owed_loss_sums())                       # the last update's logged sums
                     torch.cuda.current_stream(self.device).wait_stream(self._target_stream)   # every fork rejoins
             self._grad_norm = single_norm
             self._g_multi = (K, gm, rows)

@@ -288,17 +288,28 @@ __global__ void __launch_bounds__(256) agent_episode_kernel(const macjd_agent_ep
 // the 64 units) as in agent_episode_kernel — and the first arg-max of the eval head (its two halves meet through LDS)
 // picks the target head's value.  (Round 2 used two of the four waves for the all-action phase: 156 us at A = 33.)
 template <int A>
-__global__ void __launch_bounds__(256) qhead_double_q_kernel(const macjd_doubleq_io io) {
+struct DoubleQLds {
+    alignas(16) float Hs[2][16 * EP_LD];    // h rows of the eval / target unroll
+    alignas(16) float Bs[2][16 * EP_LD];    // base of the eval / target head
+    float Wq[2][(A + 2) * EP_H];
+    float amax_q[2][16];
+    int amax_i[2][16];
+};
+
+// (the body is a device function of (arguments, workgroup index, LDS) so that macjd_qheads_pair can run it beside the
+// taken-action Q-head in ONE launch)
+template <int A>
+__device__ __forceinline__ void qhead_double_q_body(const macjd_doubleq_io& io, const int blk, DoubleQLds<A>& L) {
     constexpr int AH = (A + 1) / 2;                                      // actions per half (the second half may hold one less)
-    __shared__ __attribute__((aligned(16))) float Hs[2][16 * EP_LD];    // h rows of the eval / target unroll
-    __shared__ __attribute__((aligned(16))) float Bs[2][16 * EP_LD];    // base of the eval / target head
-    __shared__ float Wq[2][(A + 2) * EP_H];
-    __shared__ float amax_q[2][16];
-    __shared__ int amax_i[2][16];
+    auto& Hs = L.Hs;
+    auto& Bs = L.Bs;
+    auto& Wq = L.Wq;
+    auto& amax_q = L.amax_q;
+    auto& amax_i = L.amax_i;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, g = lane >> 4;
-    const int64_t n0 = (int64_t)blockIdx.x * 16;
+    const int64_t n0 = (int64_t)blk * 16;
     const bool same_h = (io.h_e == io.h_t) && (io.he_ld == io.ht_ld);
     // weight fragments + this lane's bias of both heads
     f32x4 Be[EP_KQ], Bt[EP_KQ];
@@ -409,22 +420,36 @@ __global__ void __launch_bounds__(256) qhead_double_q_kernel(const macjd_doubleq
     }
 }
 
+template <int A>
+__global__ void __launch_bounds__(256) qhead_double_q_kernel(const macjd_doubleq_io io) {
+    __shared__ DoubleQLds<A> L;
+    qhead_double_q_body<A>(io, blockIdx.x, L);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Taken-action Q-values of the learner in one launch (include/macjd_nets.h, macjd_qtaken_io).
 constexpr int QT_TILES = 2;       // 16-row MFMA tiles per workgroup: 32 rows (303 workgroups for the update's 9 696 rows)
 constexpr int QT_AMAX = 64;
 
-__global__ void __launch_bounds__(256) qhead_taken_kernel(const macjd_qtaken_io io) {
-    __shared__ __attribute__((aligned(16))) float Hl[QT_TILES][16 * EP_LD];   // h rows of the workgroup
-    __shared__ float Wc[(QT_AMAX + 1) * EP_H];                                // W1[u][H + a] at [a][u], a = A: power column
-    __shared__ float Qp[4][QT_TILES * 16];                                    // per-wave partial sums of q
-    __shared__ int s_idx[QT_TILES * 16];
-    __shared__ float s_P[QT_TILES * 16];
+struct QtakenLds {
+    alignas(16) float Hl[QT_TILES][16 * EP_LD];   // h rows of the workgroup
+    float Wc[(QT_AMAX + 1) * EP_H];               // W1[u][H + a] at [a][u], a = A: power column
+    float Qp[4][QT_TILES * 16];                   // per-wave partial sums of q
+    int s_idx[QT_TILES * 16];
+    float s_P[QT_TILES * 16];
+};
+
+__device__ __forceinline__ void qhead_taken_body(const macjd_qtaken_io& io, const int blk, QtakenLds& L) {
+    auto& Hl = L.Hl;
+    auto& Wc = L.Wc;
+    auto& Qp = L.Qp;
+    auto& s_idx = L.s_idx;
+    auto& s_P = L.s_P;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, g = lane >> 4;
     const int A = io.A, W = EP_H + A + 1;
-    const int64_t r0 = (int64_t)blockIdx.x * (16 * QT_TILES);
+    const int64_t r0 = (int64_t)blk * (16 * QT_TILES);
     // weight fragments of this wave's 16 units (B operands), bias, second-layer weight
     f32x4 Bq[EP_KQ];
 #pragma unroll
@@ -493,13 +518,33 @@ __global__ void __launch_bounds__(256) qhead_taken_kernel(const macjd_qtaken_io 
     }
 }
 
+__global__ void __launch_bounds__(256) qhead_taken_kernel(const macjd_qtaken_io io) {
+    __shared__ QtakenLds L;
+    qhead_taken_body(io, blockIdx.x, L);
+}
+
+// Both Q-head launches of one learner update — the taken-action values of the eval head (autograd's forward) and the
+// Double-DQN target values — as ONE grid: workgroups [0, n_taken) run the first body, the rest the second.  The two
+// read the same hidden states and neither reads the other's output; as two launches they sat on two hardware queues and
+// the update's serial chain paid a cross-queue hand-over (~10 us) to meet again.
+template <int A>
+__global__ void __launch_bounds__(256) qheads_pair_kernel(const macjd_qtaken_io tio, const macjd_doubleq_io dio, const int n_taken) {
+    __shared__ union PairLds {
+        QtakenLds t;
+        DoubleQLds<A> d;
+        __device__ PairLds() {}
+    } L;
+    if ((int)blockIdx.x < n_taken) qhead_taken_body(tio, blockIdx.x, L.t);
+    else qhead_double_q_body<A>(dio, (int)blockIdx.x - n_taken, L.d);
+}
+
 }  // namespace macjd
 
 extern "C" int macjd_qhead_taken_supported(int32_t H, int32_t A) {
     return (H == macjd::EP_H && A >= 1 && A <= macjd::QT_AMAX) ? 1 : 0;
 }
 
-extern "C" int macjd_qhead_taken(const macjd_qtaken_io* io, void* hip_stream) {
+static int qtaken_check(const macjd_qtaken_io* io) {
     using namespace macjd;
     if (!io) return set_err(MACJD_EINVAL, "%s", "macjd_qhead_taken: NULL io");
     if (!macjd_qhead_taken_supported(io->H, io->A)) return set_err(MACJD_EUNSUPPORTED, "%s", "macjd_qhead_taken: unsupported H / A");
@@ -508,6 +553,13 @@ extern "C" int macjd_qhead_taken(const macjd_qtaken_io* io, void* hip_stream) {
     if ((io->idx_elem_size != 4 && io->idx_elem_size != 8) || io->h_ld < io->H || (io->h_ld & 3) || (((uintptr_t)io->h) & 15) ||
         io->w1_ld < io->H + io->A + 1 || io->act_ld < io->H || (io->x && io->x_ld < io->H + io->A + 1))
         return set_err(MACJD_EINVAL, "%s", "macjd_qhead_taken: bad stride / alignment / index size");
+    return MACJD_OK;
+}
+
+extern "C" int macjd_qhead_taken(const macjd_qtaken_io* io, void* hip_stream) {
+    using namespace macjd;
+    const int rc = qtaken_check(io);
+    if (rc != MACJD_OK) return rc;
     if (io->n_rows == 0) return MACJD_OK;
     const dim3 grid((unsigned)((io->n_rows + 16 * QT_TILES - 1) / (16 * QT_TILES)));
     hipLaunchKernelGGL(qhead_taken_kernel, grid, dim3(256), 0, (hipStream_t)hip_stream, *io);
@@ -520,7 +572,7 @@ extern "C" int macjd_qhead_double_q_supported(int32_t H, int32_t A) {
     return (H == macjd::EP_H) && (A == 5 || A == 9 || A == 17 || A == 33);
 }
 
-extern "C" int macjd_qhead_double_q(const macjd_doubleq_io* io, void* hip_stream) {
+static int doubleq_check(const macjd_doubleq_io* io) {
     using namespace macjd;
     if (!io) return set_err(MACJD_EINVAL, "%s", "macjd_qhead_double_q: NULL io");
     if (!macjd_qhead_double_q_supported(io->H, io->A))
@@ -531,6 +583,34 @@ extern "C" int macjd_qhead_double_q(const macjd_doubleq_io* io, void* hip_stream
     if (io->he_ld < io->H || io->ht_ld < io->H || io->pe_ld < io->A || io->pt_ld < io->A || io->w1e_ld < io->H + io->A + 1 ||
         io->w1t_ld < io->H + io->A + 1)
         return set_err(MACJD_EINVAL, "%s", "macjd_qhead_double_q: row stride smaller than the row");
+    return MACJD_OK;
+}
+
+extern "C" int macjd_qheads_pair(const macjd_qtaken_io* taken, const macjd_doubleq_io* dq, void* hip_stream) {
+    using namespace macjd;
+    int rc = qtaken_check(taken);
+    if (rc != MACJD_OK) return rc;
+    rc = doubleq_check(dq);
+    if (rc != MACJD_OK) return rc;
+    if (taken->A != dq->A) return set_err(MACJD_EINVAL, "%s", "macjd_qheads_pair: the two heads differ in A");
+    const int64_t nt = (taken->n_rows + 16 * QT_TILES - 1) / (16 * QT_TILES), nd = (dq->n_rows + 15) / 16;
+    if (nt + nd == 0) return MACJD_OK;
+    if (nt + nd > 0x7fffffff) return set_err(MACJD_EINVAL, "%s", "macjd_qheads_pair: too many rows for one grid");
+    const dim3 grid((unsigned)(nt + nd)), block(256);
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (dq->A == 5) hipLaunchKernelGGL((qheads_pair_kernel<5>), grid, block, 0, s, *taken, *dq, (int)nt);
+    else if (dq->A == 9) hipLaunchKernelGGL((qheads_pair_kernel<9>), grid, block, 0, s, *taken, *dq, (int)nt);
+    else if (dq->A == 17) hipLaunchKernelGGL((qheads_pair_kernel<17>), grid, block, 0, s, *taken, *dq, (int)nt);
+    else hipLaunchKernelGGL((qheads_pair_kernel<33>), grid, block, 0, s, *taken, *dq, (int)nt);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_qheads_pair: %s", hipGetErrorString(err));
+    return MACJD_OK;
+}
+
+extern "C" int macjd_qhead_double_q(const macjd_doubleq_io* io, void* hip_stream) {
+    using namespace macjd;
+    const int rc = doubleq_check(io);
+    if (rc != MACJD_OK) return rc;
     if (io->n_rows == 0) return MACJD_OK;
     const dim3 grid((unsigned)((io->n_rows + 15) / 16)), block(256);
     hipStream_t s = (hipStream_t)hip_stream;

@@ -114,17 +114,29 @@ __device__ __forceinline__ float mx_v_raw(const float* __restrict__ Hs, const fl
     return s + bV2;
 }
 
-template <int J, int SQ, bool SAVE>
-__global__ void __launch_bounds__(256) mixer_fused_forward_kernel(const macjd_mixerf_io io) {
+// LDS of one forward workgroup (the body below is a device function of (arguments, workgroup index, LDS): the eval and
+// the target mixer of one learner update run as ONE grid, macjd_mixer_fused_forward_pair)
+template <int SQ>
+struct MixerFwdLds {
+    alignas(16) float As[16 * (16 * SQ + 8)];
+    alignas(16) float Hs[16 * MX_LDH];
+    float part[4][16];
+};
+
+// LATE2: the second layers' fragments (B2 / Bf, 32 (J + 1) registers) are requested behind the first layer's MFMAs
+// instead of at the top: ~130 fewer live registers at J = 3 — two workgroups per CU, which the paired launch (twice the
+// workgroups) needs to stay one round — for one exposed L2 latency, which the CU's other workgroup covers.
+template <int J, int SQ, bool SAVE, bool LATE2 = false>
+__device__ __forceinline__ void mixer_fused_forward_body(const macjd_mixerf_io& io, const int blk, MixerFwdLds<SQ>& L) {
     constexpr int LDA = 16 * SQ + 8;
     constexpr int T1W = MX_N1 / 16 / 4;   // 6 first-layer column tiles per wave
-    __shared__ __attribute__((aligned(16))) float As[16 * LDA];
-    __shared__ __attribute__((aligned(16))) float Hs[16 * MX_LDH];
-    __shared__ float part[4][16];
+    auto& As = L.As;
+    auto& Hs = L.Hs;
+    auto& part = L.part;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, g = lane >> 4;
-    const int64_t m0 = (int64_t)blockIdx.x * 16;
+    const int64_t m0 = (int64_t)blk * 16;
     const int S = io.S;
 
     // ---- loads, oldest first = needed first (s_waitcnt counts in issue order): the state rows of the LayerNorm, then
@@ -154,9 +166,12 @@ __global__ void __launch_bounds__(256) mixer_fused_forward_kernel(const macjd_mi
     f32x4 B1[T1W][SQ], B2[J][MX_KQ2], Bf[MX_KQ2];
 #pragma unroll
     for (int i = 0; i < T1W; ++i) mx_load_frags<SQ, true>(B1[i], io.W1, S, 16 * (T1W * wave + i) + li, g);
+    auto load_second = [&]() {
 #pragma unroll
-    for (int j = 0; j < J; ++j) mx_load_frags<MX_KQ2, false>(B2[j], io.W2, MX_HH, j * MX_EM + 16 * wave + li, g);
-    mx_load_frags<MX_KQ2, false>(Bf, io.Wf2, MX_HH, 16 * wave + li, g);
+        for (int j = 0; j < J; ++j) mx_load_frags<MX_KQ2, false>(B2[j], io.W2, MX_HH, j * MX_EM + 16 * wave + li, g);
+        mx_load_frags<MX_KQ2, false>(Bf, io.Wf2, MX_HH, 16 * wave + li, g);
+    };
+    if (!LATE2) load_second();
     // this lane's rows of q (rows 4g..4g+3 of the tile), for the tail
     float qv[4][J];
 #pragma unroll
@@ -214,6 +229,7 @@ __global__ void __launch_bounds__(256) mixer_fused_forward_kernel(const macjd_mi
 #pragma unroll
                 for (int i = 0; i < T1W; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], B1[i][Q][jj], acc[i], 0, 0, 0);
         }
+        if (LATE2) load_second();
 #pragma unroll
         for (int i = 0; i < T1W; ++i) {
             const int col = 16 * (T1W * wave + i) + li;
@@ -249,6 +265,20 @@ __global__ void __launch_bounds__(256) mixer_fused_forward_kernel(const macjd_mi
         const int64_t m = m0 + li;
         if (m < io.M) io.y[m] = ((part[0][li] + part[1][li]) + (part[2][li] + part[3][li])) + mx_clamp(v_raw, -5.0f, 5.0f);
     }
+}
+
+template <int J, int SQ, bool SAVE>
+__global__ void __launch_bounds__(256) mixer_fused_forward_kernel(const macjd_mixerf_io io) {
+    __shared__ MixerFwdLds<SQ> L;
+    mixer_fused_forward_body<J, SQ, SAVE>(io, blockIdx.x, L);
+}
+
+// blockIdx.y = 0: the mixer whose activations are saved for a backward (io_a), 1: the plain one (io_b)
+template <int J, int SQ>
+__global__ void __launch_bounds__(256, (J <= 3) ? 2 : 1) mixer_fused_forward_pair_kernel(const macjd_mixerf_io io_a, const macjd_mixerf_io io_b) {
+    __shared__ MixerFwdLds<SQ> L;
+    if (blockIdx.y == 0) mixer_fused_forward_body<J, SQ, true, (J <= 3)>(io_a, blockIdx.x, L);
+    else mixer_fused_forward_body<J, SQ, false, (J <= 3)>(io_b, blockIdx.x, L);
 }
 
 // Backward (see the header): recompute the second layers from `act`, tail gradients, transposed second layers.
@@ -482,19 +512,19 @@ __device__ __forceinline__ void mx_wf_tile(const float* __restrict__ Hs, const f
 }
 
 template <int J, int SQ, bool SAVE, int PJ>
-__global__ void __launch_bounds__(256) mixer_fused_forward_wide_kernel(const macjd_mixerf_io io) {
+__device__ __forceinline__ void mixer_fused_forward_wide_body(const macjd_mixerf_io& io, const int blk, MixerFwdLds<SQ>& L) {
     static_assert(J % PJ == 0, "whole passes");
     constexpr int LDA = 16 * SQ + 8;
     constexpr int T1W = MX_N1 / 16 / 4;   // 6 first-layer column tiles per wave
     constexpr int P1W = 2;                // ... two per pass
     constexpr int NP = J / PJ;
-    __shared__ __attribute__((aligned(16))) float As[16 * LDA];
-    __shared__ __attribute__((aligned(16))) float Hs[16 * MX_LDH];
-    __shared__ float part[4][16];
+    auto& As = L.As;
+    auto& Hs = L.Hs;
+    auto& part = L.part;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, g = lane >> 4;
-    const int64_t m0 = (int64_t)blockIdx.x * 16;
+    const int64_t m0 = (int64_t)blk * 16;
     const int S = io.S;
 
     float x[SQ], lnw[SQ], lnb[SQ];
@@ -640,6 +670,19 @@ __global__ void __launch_bounds__(256) mixer_fused_forward_wide_kernel(const mac
         const int64_t m = m0 + li;
         if (m < io.M) io.y[m] = ((part[0][li] + part[1][li]) + (part[2][li] + part[3][li])) + mx_clamp(v_raw, -5.0f, 5.0f);
     }
+}
+
+template <int J, int SQ, bool SAVE, int PJ>
+__global__ void __launch_bounds__(256) mixer_fused_forward_wide_kernel(const macjd_mixerf_io io) {
+    __shared__ MixerFwdLds<SQ> L;
+    mixer_fused_forward_wide_body<J, SQ, SAVE, PJ>(io, blockIdx.x, L);
+}
+
+template <int J, int SQ, int PJ>
+__global__ void __launch_bounds__(256) mixer_fused_forward_wide_pair_kernel(const macjd_mixerf_io io_a, const macjd_mixerf_io io_b) {
+    __shared__ MixerFwdLds<SQ> L;
+    if (blockIdx.y == 0) mixer_fused_forward_wide_body<J, SQ, true, PJ>(io_a, blockIdx.x, L);
+    else mixer_fused_forward_wide_body<J, SQ, false, PJ>(io_b, blockIdx.x, L);
 }
 
 template <int J, int PJ, bool TD = false>
@@ -902,6 +945,27 @@ extern "C" int macjd_mixer_fused_forward(const macjd_mixerf_io* io, void* hip_st
 #undef MACJD_MXF
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_mixer_fused_forward: %s", hipGetErrorString(err));
+    return MACJD_OK;
+}
+
+extern "C" int macjd_mixer_fused_forward_pair(const macjd_mixerf_io* saved, const macjd_mixerf_io* plain, void* hip_stream) {
+    using namespace macjd;
+    int rc = mixerf_check(saved, false);
+    if (rc != MACJD_OK) return rc;
+    rc = mixerf_check(plain, false);
+    if (rc != MACJD_OK) return rc;
+    if (!saved->save || plain->save) return set_err(MACJD_EINVAL, "%s", "macjd_mixer_fused_forward_pair: the first mixer saves, the second does not");
+    if (saved->J != plain->J || saved->S != plain->S || saved->M != plain->M)
+        return set_err(MACJD_EINVAL, "%s", "macjd_mixer_fused_forward_pair: the two mixers differ in J / S / M");
+    if (saved->M == 0) return MACJD_OK;
+    const dim3 grid((unsigned)((saved->M + 15) / 16), 2), block(256);
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (saved->J == 2) hipLaunchKernelGGL((mixer_fused_forward_pair_kernel<2, 2>), grid, block, 0, s, *saved, *plain);
+    else if (saved->J == 3) hipLaunchKernelGGL((mixer_fused_forward_pair_kernel<3, 3>), grid, block, 0, s, *saved, *plain);
+    else if (saved->J == 6) hipLaunchKernelGGL((mixer_fused_forward_pair_kernel<6, 6>), grid, block, 0, s, *saved, *plain);
+    else hipLaunchKernelGGL((mixer_fused_forward_wide_pair_kernel<12, 12, 4>), grid, block, 0, s, *saved, *plain);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_mixer_fused_forward_pair: %s", hipGetErrorString(err));
     return MACJD_OK;
 }
 

@@ -797,8 +797,9 @@ __global__ void __launch_bounds__(1024) td_loss_kernel(const macjd_tdloss_io io)
         io.stats[0] = tot_e2 / tot_m;                                    // qmix.py:194
         io.stats[1] = tot_y / (float)M;
         io.stats[2] = tot_t / (float)M;
-        io.stats[3] = tot_m;
+        if (io.gy) io.stats[3] = tot_m;
     }
+    if (!io.gy) return;   // the logged sums only (the gradient was formed elsewhere; stats[3] belongs to the caller)
     const float scale = 2.0f / tot_m;
     const int cols = (int)io.gy_cols;
     for (int i = threadIdx.x; i < io.B * cols; i += blockDim.x) {
@@ -850,9 +851,9 @@ extern "C" int macjd_td_mask_sum(const macjd_tdloss_io* io, float* out, void* hi
 extern "C" int macjd_td_loss(const macjd_tdloss_io* io, void* hip_stream) {
     using namespace macjd;
     if (!io || io->B < 1 || io->Tm1 < 1) return set_nets_err(MACJD_EINVAL, "macjd_td_loss: bad B / Tm1");
-    if (!io->y || !io->tq || !io->reward || !io->terminated || !io->filled || !io->stats || !io->gy)
+    if (!io->y || !io->tq || !io->reward || !io->terminated || !io->filled || !io->stats)
         return set_nets_err(MACJD_EINVAL, "macjd_td_loss: NULL pointer");
-    if (io->y_sb < io->Tm1 || io->tq_sb < io->Tm1 || io->gy_cols < io->Tm1 || io->gy_sb < io->gy_cols)
+    if (io->y_sb < io->Tm1 || io->tq_sb < io->Tm1 || (io->gy && (io->gy_cols < io->Tm1 || io->gy_sb < io->gy_cols)))
         return set_nets_err(MACJD_EINVAL, "macjd_td_loss: bad strides");
     hipLaunchKernelGGL(td_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, *io);
     hipError_t err = hipGetLastError();

@@ -102,6 +102,14 @@ def qhead_double_q_from_h(h_eval, P_eval, head_eval, h_tgt, P_tgt, head_tgt, H: 
     the eval head, gather from the target head (reference core/qmix.py:138-147).  ``head_* = (W1 [H, H+A+1], b1 [H],
     w2, b2)`` of each network's fc2_q_head; h_* [N, H]; P_* [N, A]."""
     lib = _native.load()
+    io, keep, out, am = _doubleq_io(h_eval, P_eval, head_eval, h_tgt, P_tgt, head_tgt, H, A, want_argmax, p_row_map)
+    with torch.cuda.device(out.device):
+        _native.check(lib.macjd_qhead_double_q(ctypes.byref(io), _stream(out)), "macjd_qhead_double_q")
+    return (out, am) if want_argmax else out
+
+
+def _doubleq_io(h_eval, P_eval, head_eval, h_tgt, P_tgt, head_tgt, H, A, want_argmax=False, p_row_map=None):
+    """(macjd_doubleq_io, the tensors it points at, out [N], argmax [N] or None) of ``qhead_double_q_from_h``."""
     keep = []
 
     def c(t):
@@ -132,9 +140,50 @@ def qhead_double_q_from_h(h_eval, P_eval, head_eval, h_tgt, P_tgt, head_tgt, H: 
     if want_argmax:
         am = torch.empty(N, dtype=torch.int64, device=h_e.device)
         io.argmax_out = am.data_ptr()
-    with torch.cuda.device(h_e.device):
-        _native.check(lib.macjd_qhead_double_q(ctypes.byref(io), _stream(h_e)), "macjd_qhead_double_q")
-    return (out, am) if want_argmax else out
+    keep += [P_e, P_t]
+    return io, keep, out, am
+
+
+# Paired launches of the learner update (csrc: macjd_qheads_pair, macjd_mixer_fused_forward_pair).  The update's target
+# branch (Double-DQN Q-head launch -> target mixer) and its eval head (taken-action Q-head -> eval mixer, under autograd)
+# are two independent chains of two launches each; as four launches they sat on two hardware queues and the serial
+# chain paid a cross-queue hand-over where they meet.  A caller that knows both chains run ("pair_*" below, then the
+# autograd call) gets them as two grids on ONE stream: the no-grad half is prepared here — outputs allocated, argument
+# block built — and rides in the launch of the next autograd forward of the matching kind.
+_PAIRED_DQ = None      # (macjd_doubleq_io, tensors kept alive, out) waiting for the next _QheadTaken.forward
+_PAIRED_MIXER = None   # (macjd_mixerf_io, tensors kept alive, y) waiting for the next saving mixer_fused_forward
+
+
+def pair_double_q_with_next_taken(h_eval, P_eval, head_eval, h_tgt, P_tgt, head_tgt, H: int, A: int, p_row_map=None):
+    """``qhead_double_q_from_h`` whose launch happens inside the NEXT ``qhead_taken`` forward (one grid for both, on that
+    call's stream).  Returns the [N] output tensor — valid once that forward has run (``assert_pairs_launched``)."""
+    global _PAIRED_DQ
+    assert _PAIRED_DQ is None, "a paired Double-DQN launch is already waiting"
+    io, keep, out, _ = _doubleq_io(h_eval, P_eval, head_eval, h_tgt, P_tgt, head_tgt, H, A, False, p_row_map)
+    _PAIRED_DQ = (io, keep, out)
+    return out
+
+
+def pair_mixer_forward_with_next_fused(q, s, params):
+    """``mixer_fused_forward(q, s, params)`` (no activations saved) whose launch happens inside the NEXT differentiable
+    ``mixer_fused`` forward (one grid for both).  Returns y [M, 1] — valid once that forward has run."""
+    global _PAIRED_MIXER
+    assert _PAIRED_MIXER is None, "a paired mixer launch is already waiting"
+    q, s = q.detach().float().contiguous(), _f32c(s.detach())
+    y = torch.empty((s.shape[0], 1), dtype=torch.float32, device=q.device)
+    io = _mixerf_io(q, s, params)
+    io.y = y.data_ptr()
+    _PAIRED_MIXER = (io, (q, s, params), y)
+    return y
+
+
+def assert_pairs_launched():
+    """Every launch handed to ``pair_*`` has gone out (it has not if the autograd call took another code path)."""
+    global _PAIRED_DQ, _PAIRED_MIXER
+    left = [n for n, v in (("Double-DQN", _PAIRED_DQ), ("mixer", _PAIRED_MIXER)) if v is not None]
+    _PAIRED_DQ = _PAIRED_MIXER = None
+    if left:
+        raise RuntimeError("paired launch not taken by the autograd forward it was meant for: " + ", ".join(left))
 
 
 def qhead_select(base, P_all, W1, w2, b2, H: int, A: int, n_agents: int, avail: Optional[torch.Tensor],
@@ -514,8 +563,16 @@ def mixer_fused_forward(q, s, params, save=False):
         act = torch.empty((M, width), dtype=torch.float32, device=q.device)
         io.save, io.sn, io.xhat, io.act = 1, sn.data_ptr(), xhat.data_ptr(), act.data_ptr()
         saved = (sn, xhat, act)
+    global _PAIRED_MIXER
+    pair = None
+    if save:
+        pair, _PAIRED_MIXER = _PAIRED_MIXER, None
     with torch.cuda.device(q.device):
-        _native.check(lib.macjd_mixer_fused_forward(ctypes.byref(io), _stream(q)), "macjd_mixer_fused_forward")
+        if pair is not None:   # the target mixer rides in this grid (pair_mixer_forward_with_next_fused)
+            _native.check(lib.macjd_mixer_fused_forward_pair(ctypes.byref(io), ctypes.byref(pair[0]), _stream(q)),
+                          "macjd_mixer_fused_forward_pair")
+        else:
+            _native.check(lib.macjd_mixer_fused_forward(ctypes.byref(io), _stream(q)), "macjd_mixer_fused_forward")
     return y, q, saved
 
 
@@ -787,6 +844,28 @@ def td_loss_and_grad(y_full, tq_full, reward, terminated, filled, gamma, Tm1, tq
     with torch.no_grad():
         _, stats = _TdLossHip.apply(y_full, tq_full, reward, terminated, filled, gamma, Tm1, tq_off)
     return stats[0], stats[1], stats[2], stats.saved_gy, stats
+
+
+def td_loss_sums_into(row, y_full, tq_full, reward, terminated, filled, gamma, Tm1, tq_off):
+    """The logged sums of the TD loss — row[0:3] = (loss, mean(y), mean(target)), reference core/qmix.py:194, 212-213 — by
+    one launch that writes no gradient and leaves row[3] alone: for updates whose loss gradient is formed inside the
+    mixer's backward launch (``td_grad_in_mixer_backward``); this launch may then run any time later, off the chain."""
+    lib = _native.load()
+    B, Ty = y_full.shape[0], y_full.shape[1]
+    yc, tqc = y_full.detach(), tq_full.detach()
+    assert yc.dtype == torch.float32 and tqc.dtype == torch.float32 and yc.is_contiguous() and tqc.is_contiguous()
+    assert row.dtype == torch.float32 and row.numel() >= 3 and row.is_contiguous()
+    io = _native.TdLossIO()
+    io.B, io.Tm1, io.gamma = B, int(Tm1), float(gamma)
+    io.y, io.y_sb = yc.data_ptr(), Ty
+    io.tq, io.tq_sb = tqc.data_ptr() + 4 * int(tq_off), tqc.shape[1]
+    io.reward, io.r_sb, io.r_st = reward.data_ptr(), reward.stride(0), reward.stride(1)
+    io.terminated, io.t_sb, io.t_st = terminated.data_ptr(), terminated.stride(0), terminated.stride(1)
+    io.filled, io.f_sb, io.f_st = filled.data_ptr(), filled.stride(0), filled.stride(1)
+    io.stats, io.gy = row.data_ptr(), None
+    with torch.cuda.device(yc.device):
+        _native.check(lib.macjd_td_loss(ctypes.byref(io), _stream(yc)), "macjd_td_loss")
+    return row
 
 
 def td_mask_sum(filled, Tm1):
@@ -1453,8 +1532,13 @@ class _QheadTaken(torch.autograd.Function):
         io.W1, io.w1_ld, io.b1, io.w2 = w1c.data_ptr(), w1c.stride(0), b1c.data_ptr(), w2c.data_ptr()
         io.b2 = _f32c(b2.detach()).data_ptr() if b2 is not None else None
         io.x, io.x_ld, io.act, io.act_ld, io.q = x.data_ptr(), x.stride(0), act.data_ptr(), act.stride(0), q.data_ptr()
+        global _PAIRED_DQ
+        pair, _PAIRED_DQ = _PAIRED_DQ, None
         with torch.cuda.device(h.device):
-            _native.check(lib.macjd_qhead_taken(ctypes.byref(io), _stream(h)), "macjd_qhead_taken")
+            if pair is not None:   # the update's Double-DQN launch rides in this grid (pair_double_q_with_next_taken)
+                _native.check(lib.macjd_qheads_pair(ctypes.byref(io), ctypes.byref(pair[0]), _stream(h)), "macjd_qheads_pair")
+            else:
+                _native.check(lib.macjd_qhead_taken(ctypes.byref(io), _stream(h)), "macjd_qhead_taken")
         ctx.save_for_backward(x, w1, act, w2)
         ctx.has_b2, ctx.b1_key, ctx.b2_key = b2 is not None, grad_key(b1), grad_key(b2)
         return q

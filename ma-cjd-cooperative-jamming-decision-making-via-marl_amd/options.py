@@ -14,6 +14,8 @@ for normal operation.
     MACJD_LN_IN_SQNORM        1 | 0      LayerNorm-parameter gradients inside the optimiser's first launch
     MACJD_WGRAD_OUTER         1 | 0      Q-head ReLU-backward operand formed inside the weight-gradient launch
     MACJD_QHEAD_TAKEN         1 | 0      taken-action Q-head as one launch / input rows + GEMM + row-dot
+    MACJD_PAIRED_HEADS        1 | 0      pipelined update: both Q-head launches as one grid and both mixers as one grid on
+                                         the chain's stream / target branch on the side stream beside the eval head
     MACJD_GRAPHED_ALLREDUCE   0 | 1      with ranks: RCCL all-reduce captured inside the update graph
 """
 from __future__ import annotations
@@ -23,7 +25,7 @@ import os
 _DEFAULTS = {
     "UPDATE_STREAMS": "2", "UPDATES_PER_GRAPH": "1", "PIPELINED_GROUP": "1", "SHARED_BODY": "1",
     "LEARNER_STATIC_OBS": "1", "ACTOR_IN_SCAN": "1", "DEVICE_SAMPLER": "1", "LN_IN_SQNORM": "1", "WGRAD_OUTER": "1",
-    "QHEAD_TAKEN": "1", "GRAPHED_ALLREDUCE": "0",
+    "QHEAD_TAKEN": "1", "PAIRED_HEADS": "1", "GRAPHED_ALLREDUCE": "0",
 }
 _values = None
 

@@ -1739,10 +1739,14 @@ def test_graphed_updates_on_device_drawn_batches(monkeypatch):
     assert not host._g_dev_sampler and np.isfinite(host.train_from_buffer()["loss"])
 
 
-def test_updates_grouped_into_one_graph_equal_single_updates():
+@pytest.mark.parametrize("paired", ["1", "0"])
+def test_updates_grouped_into_one_graph_equal_single_updates(paired, monkeypatch):
     """train_from_buffer_many(n): groups of K updates replayed as ONE graph (each update's batch drawn on the device by
     the update before it) where no target sync falls inside the group, single replays otherwise == n calls of
-    train_from_buffer(): same draws, same statistics per update, same weights, same target syncs."""
+    train_from_buffer(): same draws, same statistics per update, same weights, same target syncs.  The pipelined updates
+    inside a group take their target branch as paired launches on the chain's stream (default) or on the side stream
+    beside the eval head (MACJD_PAIRED_HEADS=0)."""
+    monkeypatch.setenv("MACJD_PAIRED_HEADS", paired)
     from macjd_amd.core.mac import BasicMAC
     from macjd_amd.core.qmix import QMixLearner
     from macjd_amd.utils.replay_buffer import EpisodeReplayBuffer
@@ -1978,6 +1982,58 @@ def test_taken_action_qhead_in_one_launch(n, A, idt, monkeypatch):
     # the module uses it exactly when the predicate says so
     monkeypatch.setenv("MACJD_QHEAD_TAKEN", "0")
     assert not ops.qhead_taken_supported(h, w1, w2, A)
+
+
+@pytest.mark.parametrize("tag,n", [("3j4r_h64", 9696), ("6j8r_h64", 1206), ("12j16r_h64", 2412)])
+def test_paired_launches_equal_the_single_launches(tag, n):
+    """macjd_qheads_pair (taken-action Q-head + Double-DQN launch as one grid) and macjd_mixer_fused_forward_pair (saving +
+    plain mixer forward as one grid) are the single launches' bodies behind a workgroup-index switch: every output —
+    Q-values, the saved input rows / activations, both Q_tot, the gradients computed from the saved tensors — bitwise
+    equal; a pair nobody picks up is reported."""
+    from macjd_amd import ops
+    from macjd_amd.core.networks import QMixer, RNNAgent
+    g, d = load(tag)
+    args = _gpu_args(d)
+    H, A, J = d["H"], d["A"], d["J"]
+    torch.manual_seed(3)
+    with quiet():
+        ae, at = RNNAgent(d["S"], args).to(DEV), RNNAgent(d["S"], args).to(DEV)
+        me, mt = QMixer(args).to(DEV), QMixer(args).to(DEV)
+    rng = np.random.default_rng(n)
+    f = lambda *shape: torch.tensor(rng.standard_normal(shape), dtype=torch.float32, device=DEV)
+    h_e, h_t, P_all = 0.7 * f(n, H), 0.7 * f(n, H), torch.rand(n, A, device=DEV)
+    idx = torch.randint(0, A, (n, 1), device=DEV)
+    P = torch.rand(n, 1, device=DEV)
+    M = n // J
+    state = 2.0 * f(M, args.state_shape)
+    gy = f(M, 1)
+    heads = [(a.fc2_q_head[0].weight, a.fc2_q_head[0].bias, a.fc2_q_head[2].weight, a.fc2_q_head[2].bias) for a in (ae, at)]
+    params = list(ae.fc2_q_head.parameters()) + list(me.parameters())
+
+    def run(paired):
+        for p_ in params:
+            p_.grad = None
+        with torch.no_grad():
+            launch = ops.pair_double_q_with_next_taken if paired else ops.qhead_double_q_from_h
+            tq = launch(h_e, P_all, heads[0], h_t, P_all, heads[1], H, A)
+        q = ae.get_q_value_for_action(h_e, idx, P, validate=False)
+        assert type(q.grad_fn).__name__.startswith("_QheadTaken")
+        with torch.no_grad():
+            y_t = (mt.forward_paired_with_next_fused if paired else mt)(tq.view(M, J), state)
+        y_e = me(q.view(M, J), state)
+        ops.assert_pairs_launched()
+        saved = [t.clone() for t in q.grad_fn.saved_tensors[:3:2]]
+        y_e.backward(gy)
+        return [tq.clone(), q.detach().clone(), y_t.clone(), y_e.detach().clone()] + saved + [p_.grad.clone() for p_ in params]
+
+    single, pair = run(False), run(True)
+    for i, (a, b) in enumerate(zip(single, pair)):
+        assert torch.equal(a, b), i
+    with torch.no_grad():
+        ops.pair_double_q_with_next_taken(h_e, P_all, heads[0], h_t, P_all, heads[1], H, A)
+    with pytest.raises(RuntimeError, match="paired launch not taken"):
+        ops.assert_pairs_launched()
+    ops.assert_pairs_launched()   # (cleared by the report)
 
 
 def test_layernorm_param_grads_inside_the_squared_norm_launch(monkeypatch):
