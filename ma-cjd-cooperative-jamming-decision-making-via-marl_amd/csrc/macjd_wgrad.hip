@@ -221,40 +221,59 @@ __global__ void __launch_bounds__(256) wgrad_partial_kernel(const macjd_wgrad_io
     wgrad_partial_body(p, blockIdx.x, blockIdx.y, blockIdx.z, sA, sB);
 }
 
-// Sum of the K-chunk partials, fixed order (deterministic): one lane per output element, consecutive lanes = consecutive
-// n (every load instruction of a wave reads one contiguous row piece of a partial tile), eight accumulators per lane —
-// accumulator s takes chunks s, s + 8, s + 16, ... — combined as ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)).
-// (The first version spread an output's chunks over 8 LANES: 32-byte pieces of eight different tiles per load, 11 us for
-// the update's problems; same summation order.)
-__device__ __forceinline__ float wgrad_sum_chunks(const float* __restrict__ p, const int64_t stride, const int n_chunks) {
+// Sum of the K-chunk partials, fixed order (deterministic).  A workgroup owns 64 consecutive output elements; consecutive
+// lanes = consecutive n (every load instruction of a wave reads one contiguous row piece of a partial tile); the chunks
+// are taken in rounds of eight and round r belongs to wave r mod 4, so an output's <= 76 loads are in flight from four
+// waves at once instead of queueing behind one lane (one lane per output: 12.6 us for the update's problems, a
+// latency chain of ten rounds).  Order of the sum: wave w adds chunk 8 r + s (r = w, w + 4, ...) into its accumulator s,
+// combines ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)); the four waves' sums meet as (p0 + p1) + (p2 + p3).
+__device__ __forceinline__ float wgrad_sum_rounds(const float* __restrict__ p, const int64_t stride, const int n_chunks, const int wave) {
     float a[8];
 #pragma unroll
     for (int s8 = 0; s8 < 8; ++s8) a[s8] = 0.0f;
-    int c = 0;
-    for (; c + 8 <= n_chunks; c += 8) {
+    for (int c = 8 * wave; c < n_chunks; c += 32) {
         float v[8];
 #pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) v[s8] = p[(int64_t)(c + s8) * stride];
+        for (int s8 = 0; s8 < 8; ++s8) {   // (no branch around a load: past the last chunk the last chunk is read and dropped)
+            const int cc = c + s8 < n_chunks ? c + s8 : n_chunks - 1;
+            v[s8] = p[(int64_t)cc * stride];
+        }
 #pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) a[s8] += v[s8];
+        for (int s8 = 0; s8 < 8; ++s8) a[s8] += (c + s8 < n_chunks) ? v[s8] : 0.0f;
     }
-#pragma unroll
-    for (int s8 = 0; s8 < 8; ++s8)
-        if (c + s8 < n_chunks) a[s8] += p[(int64_t)(c + s8) * stride];
     return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+
+constexpr int WG_RED = 64;   // outputs per reduce workgroup
+
+// the four waves' sums of output `lane` -> the value (valid in wave 0)
+__device__ __forceinline__ float wgrad_meet(float (*part)[WG_RED], const float mine, const int wave, const int lane) {
+    part[wave][lane] = mine;
+    __syncthreads();
+    const float out = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    __syncthreads();   // (the caller's loop writes `part` again)
+    return out;
 }
 
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const macjd_wgrad_io io, const int Mp, const int Np,
                                                            const int n_chunks) {
-    const int64_t total = (int64_t)io.M * io.N;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total + io.M; i += (int64_t)gridDim.x * blockDim.x) {
+    __shared__ float part[4][WG_RED];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t total = (int64_t)io.M * io.N, all = total + (io.db ? io.M : 0);
+    for (int64_t i0 = (int64_t)blockIdx.x * WG_RED; i0 < all; i0 += (int64_t)gridDim.x * WG_RED) {
+        const int64_t i = i0 + lane < all ? i0 + lane : all - 1;   // (lanes past the end repeat the last output, never store)
+        const float* src;
+        int64_t stride;
+        float* dst;
         if (i < total) {
             const int m = (int)(i / io.N), n = (int)(i - (int64_t)m * io.N);
-            io.dW[(int64_t)m * io.dw_ld + n] = wgrad_sum_chunks(io.workspace + (int64_t)m * Np + n, (int64_t)Mp * Np, n_chunks);
-        } else if (io.db) {
+            src = io.workspace + (int64_t)m * Np + n; stride = (int64_t)Mp * Np; dst = io.dW + (int64_t)m * io.dw_ld + n;
+        } else {
             const int m = (int)(i - total);
-            io.db[m] = wgrad_sum_chunks(io.workspace + (int64_t)n_chunks * Mp * Np + m, Mp, n_chunks);
+            src = io.workspace + (int64_t)n_chunks * Mp * Np + m; stride = Mp; dst = io.db + m;
         }
+        const float v = wgrad_meet(part, wgrad_sum_rounds(src, stride, n_chunks, wave), wave, lane);
+        if (wave == 0 && i0 + lane < all) *dst = v;
     }
 }
 
@@ -296,8 +315,11 @@ __global__ void __launch_bounds__(256) wgrad_partial_many_kernel(const WgradBatc
 }
 
 __global__ void __launch_bounds__(256) wgrad_reduce_many_kernel(const WgradBatch b) {
+    __shared__ float part[4][WG_RED];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t total_all = b.out_start[b.n];
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total_all; g += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t g0 = (int64_t)blockIdx.x * WG_RED; g0 < total_all; g0 += (int64_t)gridDim.x * WG_RED) {
+        const int64_t g = g0 + lane < total_all ? g0 + lane : total_all - 1;
         int M = b.io[0].M, N = b.io[0].N, Mp = b.Mp[0], Np = b.Np[0], n_chunks = b.chunks[0];
         int64_t start = 0, dw_ld = b.io[0].dw_ld;
         const float* workspace = b.io[0].workspace;
@@ -312,12 +334,15 @@ __global__ void __launch_bounds__(256) wgrad_reduce_many_kernel(const WgradBatch
         }
         const int64_t i = g - start;
         const int64_t total = (int64_t)M * N;
-        if (i < total) {
-            const int m = (int)(i / N), n = (int)(i - (int64_t)m * N);
-            dW[(int64_t)m * dw_ld + n] = wgrad_sum_chunks(workspace + (int64_t)m * Np + n, (int64_t)Mp * Np, n_chunks);
-        } else if (db) {
-            const int m = (int)(i - total);
-            db[m] = wgrad_sum_chunks(workspace + (int64_t)n_chunks * Mp * Np + m, Mp, n_chunks);
+        // (a problem without a bias output still owns M items behind its M N: they are summed and dropped)
+        const bool is_w = i < total;
+        const int m = is_w ? (int)(i / N) : (int)(i - total);
+        const int n = is_w ? (int)(i - (int64_t)m * N) : 0;
+        const float* src = is_w ? workspace + (int64_t)m * Np + n : workspace + (int64_t)n_chunks * Mp * Np + m;
+        const float v = wgrad_meet(part, wgrad_sum_rounds(src, is_w ? (int64_t)Mp * Np : (int64_t)Mp, n_chunks, wave), wave, lane);
+        if (wave == 0 && g0 + lane < total_all) {
+            if (is_w) dW[(int64_t)m * dw_ld + n] = v;
+            else if (db) db[m] = v;
         }
     }
 }
@@ -344,8 +369,8 @@ extern "C" int macjd_linear_wgrad(const macjd_wgrad_io* io, void* hip_stream) {
     if (chunks > 65535) return set_err(MACJD_EUNSUPPORTED, "%s", "macjd_linear_wgrad: K too large");
     hipStream_t s = (hipStream_t)hip_stream;
     hipLaunchKernelGGL(wgrad_partial_kernel, dim3(Np / WG_BN, Mp / WG_BM, (unsigned)chunks), dim3(256), 0, s, *io, Mp, Np);
-    const int64_t total = (int64_t)io->M * io->N + io->M;   // one lane per output element
-    const unsigned rblocks = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    const int64_t total = (int64_t)io->M * io->N + io->M;   // WG_RED output elements per workgroup
+    const unsigned rblocks = (unsigned)((total + WG_RED - 1) / WG_RED < 8192 ? (total + WG_RED - 1) / WG_RED : 8192);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, s, *io, Mp, Np, (int)chunks);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_linear_wgrad: %s", hipGetErrorString(err));
@@ -384,7 +409,7 @@ extern "C" int macjd_linear_wgrad_many(const macjd_wgrad_io* ios, int32_t n, voi
     hipStream_t s = (hipStream_t)hip_stream;
     hipLaunchKernelGGL(wgrad_partial_many_kernel, dim3((unsigned)b.wg_start[n]), dim3(256), 0, s, b);
     const int64_t total = b.out_start[n];
-    const unsigned rblocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    const unsigned rblocks = (unsigned)((total + WG_RED - 1) / WG_RED < 8192 ? (total + WG_RED - 1) / WG_RED : 8192);
     hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3(rblocks), dim3(256), 0, s, b);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return set_err(MACJD_EDEVICE, "macjd_linear_wgrad_many: %s", hipGetErrorString(err));
