@@ -486,8 +486,10 @@ int macjd_mixer_fused_forward_pair(const macjd_mixerf_io* saved, const macjd_mix
 int macjd_mixer_fused_backward(const macjd_mixerf_io* io, void* hip_stream);
 /* macjd_mixer_fused_backward that forms dL/dy itself from the TD loss's inputs (macjd_td_loss's expression; td->y = this
    mixer's forward output, td->tq the target values, rows = td->B x td->gy_cols) and tot_m[0] = the batch's mask sum
-   (macjd_td_mask_sum): io->gy is not read, td->stats / td->gy are not written.  Takes the loss launch off the update's
-   serial chain; bit-identical gradients. */
+   (macjd_td_mask_sum): io->gy is not read, td->gy is not written.  Takes the loss launch off the update's serial chain;
+   bit-identical gradients.  td->stats != NULL: one extra workgroup of the same grid computes the loss's logged sums
+   (stats[0..2] = loss, mean(y), mean(target) — core/qmix.py:194, 212-213; stats[3] is left alone), so that they need neither
+   a launch nor a stream of their own. */
 int macjd_mixer_fused_backward_td(const macjd_mixerf_io* io, const macjd_tdloss_io* td, const float* tot_m, void* hip_stream);
 
 /*

@@ -425,27 +425,21 @@ class QMixLearner:
         # ... or, better, not beside it but INSIDE its launches: both Q-head launches as one grid and both mixers as one
         # grid on this stream (ops.pair_*): the chain no longer crosses hardware queues to meet the target branch, and
         # stays on one queue from the previous Adam to this one.
-        paired_heads = (target_beside_head and options.on("PAIRED_HEADS") and self.eval_qmix_net.fused_available(st["state"])
-                        and ops.qhead_taken_supported(st["hidden_state"].view(n, H), heads[1][0], heads[1][1], A))
+        paired_heads = target_beside_head and self._paired_heads_ok(st, T)
         if paired_heads:
             origin = torch.cuda.current_stream(dev)
-            # The NEXT update's draw / gather / scan runs beside this whole update: it forks HERE (the other staging set's
-            # last readers — the previous update — are done), but its launches are captured behind this update's backward
-            # (_finish_update): the graph runtime keeps a node on its predecessor's hardware queue only if it is that
-            # predecessor's FIRST captured dependent, and every queue change on the chain costs ~10 us.
-            # The same for the PREVIOUS update's logged loss sums (they feed nothing: launched behind this fork, any time
-            # before the group ends).  The chain then meets the side stream exactly twice per update: this fork and the
-            # wait for the prefetched scan right below it.
-            fork_here = torch.cuda.Event()
-            fork_here.record(origin)
-            owed = self._take_owed_loss_sums()
-
-            def side_work():
-                self._launch_loss_sums(owed, fork_here)
-                if after_join is not None:
-                    after_join(fork_here)
-
-            origin.wait_event(prefetched[1])     # the prefetched scan (hence the gather before it on that stream) is there
+            # Side-stream work the caller wants beside this update (after_join: the next update's prefetch) forks from this
+            # stream early, but its launches are captured behind this update's backward (_finish_update): the graph runtime
+            # keeps a node on its predecessor's hardware queue only if it is that predecessor's FIRST captured dependent,
+            # and every queue change on the chain costs ~10 us.
+            # (Measured and dropped: every prefetch of a group up front, one staging set per update, so that the chain never
+            # signals the side stream — the runtime then runs ALL side-stream nodes before the chain's first one.)
+            side_work = None
+            fork_at = torch.cuda.Event()
+            if after_join is not None:
+                side_work = lambda: after_join(fork_at)
+            if prefetched[1] is not None:        # (None: a wait earlier on this stream already covers this update's prefetch)
+                origin.wait_event(prefetched[1])  # the prefetched scan (hence the gather before it on that stream) is there
             with torch.no_grad():
                 bases = scan_chain()
                 p_eval = pre_actor[1]
@@ -456,12 +450,17 @@ class QMixLearner:
             q_taken = self.mac.agent.get_q_value_for_action(
                 st["hidden_state"].view(n, H), st["actions_discrete"].view(n, 1), st["actions_continuous"].view(n, 1),
                 validate=False).view(B, T1, J)                                                  # qmix.py:138-147, 161-184
+            if after_join is not None:
+                # (the fork: behind the Q-head grid rather than in front of it — the prefetch's scan then runs beside the
+                # weight-gradient launches instead of the two mixer launches, which it slows more: 118.2 -> 116.7 us;
+                # behind the mixer grid the prefetch is late for the next update: 120.7 us)
+                fork_at.record(origin)
             with torch.no_grad():
                 target_q_tot = self.target_qmix_net.forward_paired_with_next_fused(tq_agents, st["state"])
             eval_q_tot = self.eval_qmix_net(q_taken, st["state"])                               # qmix.py:151, 187
             ops.assert_pairs_launched()
             return self._finish_update(st, T, eval_q_tot, target_q_tot, tot_m=prefetched[2] if len(prefetched) > 2 else None,
-                                       side_work=side_work)
+                                       side_work=side_work, sums_in_backward=True)
         elif target_beside_head:
             origin = torch.cuda.current_stream(dev)
             ts = self._target_stream
@@ -534,27 +533,19 @@ class QMixLearner:
             eval_q_tot = eval_forward()
         return self._finish_update(st, T, eval_q_tot, target_q_tot)
 
-    def _take_owed_loss_sums(self):
-        owed, self._owed_loss_sums = getattr(self, "_owed_loss_sums", None), None
-        return owed
+    def _paired_heads_ok(self, st, T):
+        """A prefetched update can take its target branch as paired launches on the chain's stream (ops.pair_*): HIP device,
+        two streams, the one-launch forms of both Q-heads and both mixers apply, MACJD_PAIRED_HEADS not 0."""
+        B, T1 = st["state"].shape[0], T + 1
+        J, H, A = self.n_agents, self.args.rnn_hidden_dim, self.n_actions
+        n = B * T1 * J
+        head = self.mac.agent.fc2_q_head
+        return (st["state"].is_cuda and options.get("UPDATE_STREAMS") != "1" and options.on("PAIRED_HEADS")
+                and ops.qhead_double_q_fused_supported(st["obs"].reshape(n, -1), H, A)
+                and self.target_qmix_net.fused_available(st["state"]) and self.eval_qmix_net.fused_available(st["state"])
+                and ops.qhead_taken_supported(st["hidden_state"].view(n, H), head[0].weight, head[2].weight, A))
 
-    def _launch_loss_sums(self, owed, fork=None):
-        """The logged-sums launch of an earlier update (see the paired branch of _forward_backward_full) on the side
-        stream, behind ``fork`` (an event of the origin stream; None: behind everything issued on it so far)."""
-        if owed is None:
-            return
-        row, y, tq, st, T = owed
-        ts = self._target_stream
-        if fork is None:
-            ts.wait_stream(torch.cuda.current_stream(y.device))
-        else:
-            ts.wait_event(fork)
-        with torch.cuda.stream(ts):
-            ops.td_loss_sums_into(row, y, tq, st["reward"], st["terminated"], st["filled"], self.args.gamma, T - 1, 1)
-        for t_ in (row, y, tq):
-            t_.record_stream(ts)
-
-    def _finish_update(self, st, T, eval_q_tot, target_q_tot, tot_m=None, side_work=None):
+    def _finish_update(self, st, T, eval_q_tot, target_q_tot, tot_m=None, side_work=None, sums_in_backward=False):
         # loss over eval steps 0..T-2 against targets built from target steps 1..T-1 (qmix.py:155,190-194)
         for p in self.params:
             p.grad = None
@@ -571,7 +562,7 @@ class QMixLearner:
                 origin = torch.cuda.current_stream(eval_q_tot.device)
                 ts = self._target_stream
                 head_done = torch.cuda.Event()
-                if side_work is None:
+                if not sums_in_backward:
                     head_done.record(origin)
 
                 def stats_branch():
@@ -583,18 +574,16 @@ class QMixLearner:
                         done.record(ts)
                     return out, done
 
-                if side_work is None:
+                if not sums_in_backward:
                     (loss, eval_mean, target_mean, _, self._last_stats4), stats_done = stats_branch()
                 else:
-                    # paired update: the row exists now (the optimiser writes the gradient norm into [3]); its first three
-                    # entries come from a launch that the NEXT update (or the end of the group) issues
-                    row = torch.empty(4, dtype=torch.float32, device=eval_q_tot.device)
-                    self._last_stats4 = row
-                    assert getattr(self, "_owed_loss_sums", None) is None
-                    self._owed_loss_sums = (row, eval_q_tot.detach(), target_q_tot.detach(), st, T)
+                    # paired update: the logged sums feed nothing, so they get neither a launch nor a stream of their own —
+                    # one extra workgroup of the mixer's backward launch computes them (the optimiser writes the gradient
+                    # norm into the same row later)
+                    row = self._last_stats4 = torch.empty(4, dtype=torch.float32, device=eval_q_tot.device)
                     loss, eval_mean, target_mean = row[0], row[1], row[2]
                 gy = ops.td_grad_in_mixer_backward(eval_q_tot, target_q_tot, st["reward"], st["terminated"], st["filled"],
-                                                   self.args.gamma, T - 1, 1, tot_m)
+                                                   self.args.gamma, T - 1, 1, tot_m, stats_row=row if sums_in_backward else None)
             else:
                 loss, eval_mean, target_mean, gy, self._last_stats4 = ops.td_loss_and_grad(
                     eval_q_tot, target_q_tot, st["reward"], st["terminated"], st["filled"], self.args.gamma, T - 1, 1)
@@ -804,8 +793,8 @@ class QMixLearner:
             stages = [stage, stage2]
             origin_dev = self.device
 
-            def prefetch(dst, fork=True):
-                """draw + gather + scan of the NEXT update on the side stream (called behind the current join)"""
+            def prefetch(dst, fork=True, draw=True):
+                """draw + gather + scan of a LATER update on the side stream"""
                 origin = torch.cuda.current_stream(origin_dev)
                 ts = self._target_stream
                 if isinstance(fork, torch.cuda.Event):
@@ -815,7 +804,8 @@ class QMixLearner:
                 shared = self._body_is_shared()
                 agents = [self.mac.agent] if shared else [self.target_mac.agent, self.mac.agent]
                 with torch.cuda.stream(ts), torch.no_grad():
-                    ops.sample_episodes(self._g_idx, self._g_n_stored, self._g_draws, self._sampler_seed())
+                    if draw:
+                        ops.sample_episodes(self._g_idx, self._g_n_stored, self._g_draws, self._sampler_seed())
                     ops.gather_rows(self._g_idx, srcs, [dst[k] for k in keys])
                     tot_m = ops.td_mask_sum(dst["filled"], self._g_T - 1)     # the loss's only global sum the gradient needs
                     ev_g = torch.cuda.Event()
@@ -850,7 +840,6 @@ class QMixLearner:
                     # the update's last launch draws the next batch — unless the prefetch behind the join has done so
                     self._clip_and_step(sample_next=None if nxt_batch is not None else nxt)
                 if pipelined:
-                    self._launch_loss_sums(self._take_owed_loss_sums())                       # the last update's logged sums
                     torch.cuda.current_stream(self.device).wait_stream(self._target_stream)   # every fork rejoins
             self._grad_norm = single_norm
             self._g_multi = (K, gm, rows)

@@ -27,6 +27,7 @@
 #include "../../include/macjd.h"
 #include "../../include/macjd_nets.h"
 #include "macjd_err.h"
+#include "macjd_tdloss.h"
 
 namespace macjd {
 
@@ -302,6 +303,10 @@ __global__ void __launch_bounds__(256) mixer_fused_backward_kernel(const macjd_m
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, g = lane >> 4;
+    if (TD && td.stats && blockIdx.x == gridDim.x - 1) {   // the extra workgroup: the loss's logged sums (macjd_tdloss.h)
+        td_loss_sums(td, false);
+        return;
+    }
     const int64_t m0 = (int64_t)blockIdx.x * 16;
 
     // ---- weight fragments, requested up front: forward orientation for the recomputation ...
@@ -702,6 +707,10 @@ __global__ void __launch_bounds__(256) mixer_fused_backward_wide_kernel(const ma
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, g = lane >> 4;
+    if (TD && td.stats && blockIdx.x == gridDim.x - 1) {   // the extra workgroup: the loss's logged sums (macjd_tdloss.h)
+        td_loss_sums(td, false);
+        return;
+    }
     const int64_t m0 = (int64_t)blockIdx.x * 16;
 
     f32x4 B2a[PJ][MX_KQ2], B2b[PJ][MX_KQ2], Bf[MX_KQ2];
@@ -996,7 +1005,8 @@ extern "C" int macjd_mixer_fused_backward_td(const macjd_mixerf_io* io, const ma
     if (td->gy_cols < td->Tm1 || (int64_t)td->B * td->gy_cols != io->M || td->y_sb < td->Tm1 || td->tq_sb < td->Tm1)
         return set_err(MACJD_EINVAL, "%s", "macjd_mixer_fused_backward_td: rows must be B x gy_cols with gy_cols >= Tm1");
     if (io->M == 0) return MACJD_OK;
-    const dim3 grid((unsigned)((io->M + 15) / 16)), block(256);
+    // td->stats != NULL: one workgroup more, which computes the loss's logged sums (stats[0..2]) beside the others
+    const dim3 grid((unsigned)((io->M + 15) / 16) + (td->stats ? 1u : 0u)), block(256);
     hipStream_t s = (hipStream_t)hip_stream;
     if (io->J == 2) hipLaunchKernelGGL((mixer_fused_backward_kernel<2, true>), grid, block, 0, s, *io, *td, tot_m);
     else if (io->J == 3) hipLaunchKernelGGL((mixer_fused_backward_kernel<3, true>), grid, block, 0, s, *io, *td, tot_m);

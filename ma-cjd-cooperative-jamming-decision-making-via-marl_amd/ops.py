@@ -851,6 +851,14 @@ def td_loss_sums_into(row, y_full, tq_full, reward, terminated, filled, gamma, T
     one launch that writes no gradient and leaves row[3] alone: for updates whose loss gradient is formed inside the
     mixer's backward launch (``td_grad_in_mixer_backward``); this launch may then run any time later, off the chain."""
     lib = _native.load()
+    io, keep = _tdloss_sums_io(row, y_full, tq_full, reward, terminated, filled, gamma, Tm1, tq_off)
+    with torch.cuda.device(row.device):
+        _native.check(lib.macjd_td_loss(ctypes.byref(io), _stream(row)), "macjd_td_loss")
+    return row
+
+
+def _tdloss_sums_io(row, y_full, tq_full, reward, terminated, filled, gamma, Tm1, tq_off):
+    """(macjd_tdloss_io of the sums-only form, the tensors it points at)"""
     B, Ty = y_full.shape[0], y_full.shape[1]
     yc, tqc = y_full.detach(), tq_full.detach()
     assert yc.dtype == torch.float32 and tqc.dtype == torch.float32 and yc.is_contiguous() and tqc.is_contiguous()
@@ -863,9 +871,7 @@ def td_loss_sums_into(row, y_full, tq_full, reward, terminated, filled, gamma, T
     io.terminated, io.t_sb, io.t_st = terminated.data_ptr(), terminated.stride(0), terminated.stride(1)
     io.filled, io.f_sb, io.f_st = filled.data_ptr(), filled.stride(0), filled.stride(1)
     io.stats, io.gy = row.data_ptr(), None
-    with torch.cuda.device(yc.device):
-        _native.check(lib.macjd_td_loss(ctypes.byref(io), _stream(yc)), "macjd_td_loss")
-    return row
+    return io, (row, yc, tqc, reward, terminated, filled)
 
 
 def td_mask_sum(filled, Tm1):
@@ -900,10 +906,12 @@ def fused_mixer_backward_will_run(y_full) -> bool:
     return False
 
 
-def td_grad_in_mixer_backward(y_full, tq_full, reward, terminated, filled, gamma, Tm1, tq_off, tot_m):
+def td_grad_in_mixer_backward(y_full, tq_full, reward, terminated, filled, gamma, Tm1, tq_off, tot_m, stats_row=None):
     """Arrange for the fused mixer's backward launch (started by ``y_full.backward(placeholder)``, placeholder = the return
     value) to form dL/dy of the TD loss itself from the loss's inputs and ``tot_m`` (``td_mask_sum``): no loss launch in
-    front of the backward pass.  The logged statistics are the caller's business (``td_loss_and_grad`` off the chain)."""
+    front of the backward pass.  The logged statistics: one extra workgroup of that launch writes (loss, mean y, mean
+    target) into ``stats_row[0:3]`` when given; otherwise they are the caller's business (``td_loss_and_grad`` /
+    ``td_loss_sums_into`` off the chain)."""
     global _PENDING_TD
     B, Ty = y_full.shape[0], y_full.shape[1]
     yc, tqc = y_full.detach().float().contiguous(), tq_full.detach().float().contiguous()
@@ -915,7 +923,10 @@ def td_grad_in_mixer_backward(y_full, tq_full, reward, terminated, filled, gamma
     io.reward, io.r_sb, io.r_st = reward.data_ptr(), reward.stride(0), reward.stride(1)
     io.terminated, io.t_sb, io.t_st = terminated.data_ptr(), terminated.stride(0), terminated.stride(1)
     io.filled, io.f_sb, io.f_st = filled.data_ptr(), filled.stride(0), filled.stride(1)
-    _PENDING_TD = (io, (yc, tqc, reward, terminated, filled, tot_m), B * Ty, tot_m)
+    if stats_row is not None:
+        assert stats_row.dtype == torch.float32 and stats_row.numel() >= 3 and stats_row.is_contiguous()
+        io.stats = stats_row.data_ptr()
+    _PENDING_TD = (io, (yc, tqc, reward, terminated, filled, tot_m, stats_row), B * Ty, tot_m)
     return torch.empty((B, Ty, 1), dtype=torch.float32, device=yc.device)   # never read
 
 

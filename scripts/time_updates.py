@@ -2,7 +2,7 @@
 """Microseconds per learner update of the benchmark configuration WITHOUT a profiler attached (rocprofv3 inflates exactly
 the cross-queue hand-overs one is usually trying to judge): groups of 20 updates replayed as one graph, wall clock over
 n updates, several repetitions.  Environment switches (MACJD_*) select the variant:
-    python scripts/time_updates.py [n_updates] [repetitions]"""
+    [UPG=updates per graph] [JAMMERS= RADARS=] python scripts/time_updates.py [n_updates] [repetitions]"""
 import contextlib
 import io
 import os
@@ -34,7 +34,7 @@ with contextlib.redirect_stdout(io.StringIO()):
     buf = EpisodeReplayBuffer(args, device=dev)
     learner = QMixLearner(mac, args)
 BatchedEpisodeRunner(env, mac, buf, args).run(sync_stats=False)
-learner.enable_graphs(buf, args.batch_size, updates_per_graph=20)
+learner.enable_graphs(buf, args.batch_size, updates_per_graph=int(os.environ.get("UPG", 20)))
 learner.train_from_buffer_many(200)
 torch.cuda.synchronize()
 out = []
@@ -43,5 +43,5 @@ for _ in range(reps):
     learner.train_from_buffer_many(n)
     torch.cuda.synchronize()
     out.append((time.perf_counter() - t0) / n * 1e6)
-tag = " ".join(f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("MACJD_"))
+tag = " ".join(f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("MACJD_") or k in ("UPG", "JAMMERS", "RADARS"))
 print(f"us/update [{tag or 'defaults'}]: " + " ".join(f"{x:.1f}" for x in out) + f"   min {min(out):.1f}")

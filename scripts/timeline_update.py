@@ -19,6 +19,9 @@ typical = [p for p in periods if p < 3 * statistics.median(periods)]      # (epi
 print(f"{len(ends)} updates; period between the ends of consecutive updates: median {statistics.median(periods):.1f} us, "
       f"mean of the {len(typical)} ordinary ones {statistics.mean(typical):.1f} us (the first update of a replayed group does its "
       f"draw / gather / scan itself, the others find them done)")
+mid = len(periods) // 2
+print("periods of 44 consecutive updates from the middle of the run (us; a replayed group shows as a repeating pattern): "
+      + " ".join(f"{p:.0f}" for p in periods[mid - 22:mid + 22]))
 # a window whose period is the median one
 k = min(range(len(periods) // 3, 2 * len(periods) // 3), key=lambda i: abs(periods[i] - statistics.median(periods)))
 w0, w1 = ends[k], ends[k + 1]

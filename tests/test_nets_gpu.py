@@ -1288,6 +1288,52 @@ def test_td_loss_kernel(B, T):
     np.testing.assert_allclose(yd.grad.cpu().numpy(), yr.grad.numpy(), rtol=1e-5, atol=1e-7)
 
 
+def test_logged_loss_sums_without_a_launch_of_their_own():
+    """Updates whose loss gradient is formed inside the mixer's backward launch still log (loss, mean Q_tot, mean target):
+    macjd_td_loss with gy = NULL writes stats[0..2] only, and macjd_mixer_fused_backward_td with td->stats computes the same
+    three values in one extra workgroup of the backward launch — equal to the full loss launch's values to float rounding
+    (the block sums are grouped differently), row[3] untouched, the backward's gradients bitwise unchanged."""
+    from macjd_amd import ops
+    from macjd_amd.core.networks import QMixer
+    g_, d = load("3j4r_h64")
+    B, T, J = 32, 101, d["J"]
+    args = _gpu_args(d)
+    torch.manual_seed(2)
+    mixer = QMixer(args).to(DEV)
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(B, T, J, generator=g).to(DEV).requires_grad_(True)
+    state = torch.randn(B, T, args.state_shape, generator=g).to(DEV)
+    tq = torch.randn(B, T, 1, generator=g).to(DEV)
+    reward = torch.randn(B, T, 1, generator=g).to(DEV)
+    lens = torch.randint(2, T, (B,), generator=g)
+    steps = torch.arange(T).view(1, T, 1)
+    filled, terminated = (steps < lens.view(B, 1, 1)).to(DEV), (steps >= (lens.view(B, 1, 1) - 1)).to(DEV)
+    params = [q] + list(mixer.parameters())
+
+    def run(row):
+        for p_ in params:
+            p_.grad = None
+        y = mixer(q, state)
+        tot_m = ops.td_mask_sum(filled, T - 1)
+        assert ops.fused_mixer_backward_will_run(y)
+        gy = ops.td_grad_in_mixer_backward(y, tq, reward, terminated, filled, 0.99, T - 1, 1, tot_m, stats_row=row)
+        y.backward(gy)
+        return y.detach(), [p_.grad.clone() for p_ in params]
+
+    y0, g0 = run(None)
+    row = torch.full((4,), -7.0, device=DEV)
+    y1, g1 = run(row)
+    for a_, b_ in zip(g0, g1):
+        assert torch.equal(a_, b_)
+    full = ops.td_loss_and_grad(y0, tq, reward, terminated, filled, 0.99, T - 1, 1)[4]
+    np.testing.assert_allclose(row[:3].cpu().numpy(), full[:3].cpu().numpy(), rtol=2e-6)
+    assert float(row[3]) == -7.0
+    alone = torch.full((4,), -7.0, device=DEV)
+    ops.td_loss_sums_into(alone, y0, tq, reward, terminated, filled, 0.99, T - 1, 1)
+    np.testing.assert_allclose(alone[:3].cpu().numpy(), full[:3].cpu().numpy(), rtol=2e-6)
+    assert float(alone[3]) == -7.0
+
+
 @pytest.mark.parametrize("max_norm", [1.0, 1e6])
 def test_fused_clip_adam_vs_torch(max_norm):
     """Fused clip_grad_norm_ + Adam on a flat vector == torch.nn.utils.clip_grad_norm_ + torch.optim.Adam over
