@@ -5,9 +5,9 @@
 // In the learner's backward these products have tiny outputs (hyper-network and Q-head weights, 64..384 x 46..128)
 // and a long reduction (K = B (T+1) = 3232 mixer rows, or B (T+1) J = 9696 agent rows).  A library GEMM tiles the
 // OUTPUT, i.e. runs them on 6..12 workgroups for 25..50 us each; here the REDUCTION is tiled:
-//   * grid = (N tiles, M tiles, K chunks), 64 x 64 output tile x 128-row chunk per workgroup (4 waves as 2 x 2,
+//   * grid = (N tiles, M tiles, K chunks), 64 x 64 output tile x 64-row chunk (WG_KC) per workgroup (4 waves as 2 x 2,
 //     32 x 32 per wave = 2 x 2 accumulators of v_mfma_f32_16x16x4_f32);
-//   * both operand chunks are staged into LDS with coalesced 16-byte loads, [128][80] floats each (row pitch
+//   * both operand chunks are staged into LDS with coalesced 16-byte loads, [WG_KC][80] floats each (row pitch
 //     80 = 16 mod 32: the fragment reads `chunk[4 kk + (lane >> 4)][16 t + (lane & 15)]` of both operands hit 32
 //     distinct banks per 32-lane group);
 //   * the chunk's partial tile goes to workspace[chunk][M][N]; the bias partial (column sums of the staged gout
@@ -24,13 +24,16 @@ namespace macjd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef MACJD_WG_KC
-#define MACJD_WG_KC 128   // rows of the reduction per workgroup (tuning knob: -DMACJD_WG_KC=64 halves LDS per workgroup)
+#define MACJD_WG_KC 64    // rows of the reduction per work item: 41 KB of LDS, three workgroups per CU.  (128 rows = 82 KB = ONE
+                          // workgroup per CU, whose load / multiply / store phases then never overlap another's: update 117.1 us
+                          // vs 111.5; 32 rows: 115.9 — twice the partial tiles again.  With the one-lane-per-output reduce of
+                          // round 2 the extra partials of 64-row items cost what the partial launch gained.)
 #endif
 #ifndef MACJD_WG_ABLATE
 #define MACJD_WG_ABLATE 0   // timing-only builds (scripts/probe_wgrad.py): 1 no MFMA loop, 2 no global loads, 4 no partial store
 #endif
 #ifndef MACJD_WG_SUB
-#define MACJD_WG_SUB 1      // 128-row pieces per work item (2: piece s + 1 is loaded into registers while piece s is multiplied —
+#define MACJD_WG_SUB 1      // WG_KC-row pieces per work item (2: piece s + 1 is loaded into registers while piece s is multiplied —
                             // measured slower on the update's problems: 18.3 vs 11.7 us, half the workgroups with twice the latency each)
 #endif
 constexpr int WG_BM = 64, WG_BN = 64, WG_KC = MACJD_WG_KC, WG_PITCH = 80, WG_SUB = MACJD_WG_SUB;
@@ -56,7 +59,7 @@ __device__ __forceinline__ void wgrad_partial_body(const WgradProb& io, const in
     const int m0 = tm * WG_BM, n0 = tn * WG_BN;
     const int64_t k0 = (int64_t)chunk * WG_ROWS;
     const int tid = threadIdx.x;
-    // ---- a 128-row piece of both operands: 64 columns, 16 threads per row, 16-byte loads where aligned.  The piece is
+    // ---- a WG_KC-row piece of both operands: 64 columns, 16 threads per row, 16-byte loads where aligned.  The piece is
     // loaded into registers (8 x 2 float4 per thread) and written to LDS in a second step, so that the loads of piece
     // s + 1 are in flight while piece s is multiplied (measured on the update's seven problems: loads ~10 us and MFMA
     // ~8 us of the launch were additive when each work item was load -> barrier -> multiply) ----
