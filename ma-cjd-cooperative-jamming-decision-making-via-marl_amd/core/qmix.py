@@ -829,7 +829,18 @@ class QMixLearner:
                     elif pipelined:
                         pre = self._scan_from_ring_early()
                         ops.gather_rows(self._g_idx, srcs, [stage[k] for k in keys])
-                        self._forward_backward_full(stage, self._g_T, pre_scan=pre[0], pre_actor=pre[1], after_join=hook)
+                        if self._paired_heads_ok(stage, self._g_T):
+                            # the group's first update in the paired form too: its scan (side stream) and its gather + mask
+                            # sum (this stream) run beside each other, then the same chain as every other update — and the
+                            # second update's prefetch forks as early as everyone's (first two updates of a group:
+                            # 169 + 134 -> 150 + 111 us)
+                            tot_m0 = ops.td_mask_sum(stage["filled"], self._g_T - 1)
+                            scan_done = torch.cuda.Event()
+                            scan_done.record(self._target_stream)
+                            self._forward_backward_full(stage, self._g_T, pre_scan=pre[0], pre_actor=pre[1],
+                                                        prefetched=(None, scan_done, tot_m0), after_join=hook)
+                        else:
+                            self._forward_backward_full(stage, self._g_T, pre_scan=pre[0], pre_actor=pre[1], after_join=hook)
                     else:
                         body_a()
                     nxt_batch = box.get("next")
