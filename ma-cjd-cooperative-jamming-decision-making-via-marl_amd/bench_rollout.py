@@ -119,7 +119,7 @@ def make_step(cli, sc, env, dev, rank, world, mode):
             learner.enable_graphs(buf, args.batch_size, updates_per_graph=int(os.environ.get("MACJD_UPDATES_PER_GRAPH", "20")))
     tails = set()
     fused_rollout = use_graphs and runner.fused_rollout_available()
-    if use_graphs and not fused_rollout:
+    if use_graphs:   # (fused rollout: reset + fills + the whole-episode launches as one graph; else the step-by-step loop)
         runner.enable_graph()
         # the partial episode at the end of the warm-up / timed region gets its own (shorter) graph, so every step of
         # the run is replayed from a graph whatever --steps / --warmup are

@@ -277,8 +277,9 @@ class BatchedEpisodeRunner:
         dev = self.device
         if getattr(self, "_graphs", None) is None:
             self._graphs = {}
-            self._eps_sched = torch.zeros(T, dtype=torch.float32, device=dev)
-            self._ctr_base = torch.zeros(1, dtype=torch.int64, device=dev)
+            if getattr(self, "_eps_sched", None) is None:
+                self._eps_sched = torch.zeros(T, dtype=torch.float32, device=dev)
+                self._ctr_base = torch.zeros(1, dtype=torch.int64, device=dev)
         t_env0, ep0 = self.t_env, self._ep
         # the warm-up rollout resets the envs: put their episode indices (Monte-Carlo stream position) back afterwards,
         # so that enabling a graph does not change which values the following episodes draw
@@ -314,6 +315,9 @@ class BatchedEpisodeRunner:
     def _rollout_body(self, device_schedule=False, n_steps=None):
         T = self.episode_limit if n_steps is None else n_steps
         self.begin_episodes()
+        if device_schedule and self.fused_rollout_available():
+            self._fused_launches(T)     # whole-episode launches (static observation): the same rows as the loop below
+            return
         for t in range(T):
             if device_schedule:
                 self.mac.device_schedule = (self._eps_sched[t:t + 1], self._ctr_base, t + 1)
@@ -389,9 +393,24 @@ class BatchedEpisodeRunner:
         eps = np.zeros(T, dtype=np.float32)
         for t in range(n):
             eps[t] = sel.anneal(self.t_env + t, test_mode=test_mode)
+        if not test_mode and n in (getattr(self, "_graphs", None) or {}):
+            # the batch's device work — reset, fills, the three launches — was captured (enable_graph): two small uploads
+            # and ONE graph launch instead of ~10 eager launches (~200 us of host time, which a short run cannot hide)
+            return self.rollout_graphed(n)
         self._upload_eps_schedule(eps)
         self.begin_episodes()                       # episode index, zero hidden state, env reset, static rows + inputs
         self._ctr_base.fill_(self._ep * (T + 1))
+        self._fused_launches(n, test_mode=test_mode)
+        self.t_env += n
+
+    def _fused_launches(self, n, test_mode=False):
+        """The whole-episode launches of ``rollout_fused`` for the first ``n`` steps (behind ``begin_episodes``; exploration
+        schedule and Philox counter base are read from device memory)."""
+        from .. import ops
+        st, mac, env = self.stage, self.mac, self.env
+        E, J = self.batch_envs, self.n_agents
+        if getattr(self, "_rdpj_steps", None) is None:
+            self._rdpj_steps = torch.zeros((self.episode_limit, E, 3), dtype=torch.float32, device=self.device)
         params, gi = mac.static_inputs
         a = mac.agent
         l1, l2 = a.fc2_q_head[0], a.fc2_q_head[2]
@@ -400,7 +419,6 @@ class BatchedEpisodeRunner:
                           st["hidden_state"], st["actions_discrete"], st["actions_continuous"], h_final=mac.hidden_states)
         env.step_many(st["actions_discrete"][:n], st["actions_continuous"][:n], st["reward"][:n], st["terminated"][:n],
                       self._rdpj_steps[:n], rdpj_sum=self._rdpj_sum)
-        self.t_env += n
 
     def run(self, test_mode=False, store=True, sync_stats=True):
         """One batch of E episodes.  Returns the reference's ``run_info`` keys as means over the E

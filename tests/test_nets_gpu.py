@@ -796,9 +796,12 @@ def test_shared_agent_body_equals_two_controller_unroll(monkeypatch):
     assert learner._body_is_shared()
 
 
-def test_graphed_rollout_equals_eager_rollout():
-    """One HIP-graph launch per episode batch == step-by-step launches: identical actions, rewards,
-    hidden states over two consecutive episode batches (epsilon annealing + Philox counters advance)."""
+@pytest.mark.parametrize("fused", [False, True])
+def test_graphed_rollout_equals_eager_rollout(fused):
+    """One HIP-graph launch per episode batch == eager launches — of the step-by-step rollout, and of the whole-episode
+    (fused) rollout, whose reset / fills / three launches are captured as one graph too: identical actions, rewards,
+    hidden states over two consecutive episode batches (epsilon annealing + Philox counters advance), and over a batch cut
+    after 20 steps (its own, shorter graph)."""
     from macjd_amd.core.mac import BasicMAC
     from macjd_amd.runners.episode_runner import BatchedEpisodeRunner
     from macjd_amd.simulation.environment import BatchedElectromagneticEnvironment
@@ -818,11 +821,15 @@ def test_graphed_rollout_equals_eager_rollout():
             mac.cuda()
             buf = EpisodeReplayBuffer(args)
         r = BatchedEpisodeRunner(env, mac, buf, args)
-        r.fused_rollout = False      # the step-by-step rollout: eager launches vs one graph replay
+        r.fused_rollout = fused
+        assert r.fused_rollout_available() == fused
         return r, buf, mac
     r_e, b_e, m_e = build()
     r_g, b_g, m_g = build()
     r_g.enable_graph()
+    if fused:
+        r_g.enable_graph(n_steps=20)
+        assert sorted(r_g._graphs) == [20, 100]
     for ep in range(2):
         ie = r_e.run(sync_stats=True)
         ig = r_g.run(sync_stats=True)
@@ -836,6 +843,12 @@ def test_graphed_rollout_equals_eager_rollout():
             np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-6, rtol=0, err_msg=k)
         else:
             assert torch.equal(a, b), k
+    if fused:   # a batch cut after 20 steps: eager launches vs the 20-step graph (same launches: bit for bit)
+        r_e.rollout_fused(n_steps=20)
+        r_g.rollout_fused(n_steps=20)
+        assert r_e.t_env == r_g.t_env == 220
+        for k in ("hidden_state", "actions_discrete", "actions_continuous", "reward", "terminated"):
+            assert torch.equal(r_e.stage[k][:20], r_g.stage[k][:20]), k
 
 
 @pytest.mark.parametrize("scenario,per_env", [("3j4r", False), ("3j4r", True), ("6j8r", False), ("2j2r_shipped", False), ("12j16r", False)])
