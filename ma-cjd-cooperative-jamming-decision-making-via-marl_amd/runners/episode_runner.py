@@ -328,11 +328,7 @@ class BatchedEpisodeRunner:
         """Enqueue one episode batch (or its first ``n_steps`` steps) by replaying the captured graph (training mode)."""
         T = self.episode_limit
         n = T if n_steps is None else int(n_steps)
-        sel = self.mac.action_selector
-        eps = np.zeros(T, dtype=np.float32)
-        for t in range(n):
-            eps[t] = sel.anneal(self.t_env + t, test_mode=False)
-        self._upload_eps_schedule(eps)
+        self._upload_eps_schedule(self._eps_schedule(n, False))
         self._ep += 1
         self._ctr_base.fill_(self._ep * (T + 1))
         from .. import hipgraph
@@ -353,6 +349,21 @@ class BatchedEpisodeRunner:
         from .. import ops
         return (getattr(self.env, "kernel_flags", 0) == 0
                 and ops.agent_episode_supported(self.n_agents, agent.rnn_hidden_dim, agent.n_actions))
+
+    def _eps_schedule(self, n, test_mode):
+        """Exploration probability of the next ``n`` steps [episode_limit] float32 — the selector's ``anneal`` (reference
+        utils/action_selectors.py:30-32) for t_env, t_env + 1, ... in one vector expression (same float64 arithmetic), the
+        selector left at the last step's value as after n calls."""
+        sel = self.mac.action_selector
+        eps = np.zeros(self.episode_limit, dtype=np.float32)
+        if test_mode:
+            eps[:n] = sel.epsilon
+        else:
+            delta = (sel.epsilon_start - sel.epsilon_finish) / sel.epsilon_anneal_time
+            sched = np.maximum(sel.epsilon_finish, sel.epsilon_start - delta * (self.t_env + np.arange(n, dtype=np.float64)))
+            eps[:n] = sched
+            sel.epsilon = float(sched[-1])
+        return eps
 
     def _upload_eps_schedule(self, eps: np.ndarray):
         """The episode batch's exploration schedule -> device, through one of two pinned buffers (a copy from pageable memory
@@ -389,15 +400,11 @@ class BatchedEpisodeRunner:
             self._ctr_base = torch.zeros(1, dtype=torch.int64, device=self.device)
         if getattr(self, "_rdpj_steps", None) is None:
             self._rdpj_steps = torch.zeros((T, E, 3), dtype=torch.float32, device=self.device)
-        sel = mac.action_selector
-        eps = np.zeros(T, dtype=np.float32)
-        for t in range(n):
-            eps[t] = sel.anneal(self.t_env + t, test_mode=test_mode)
         if not test_mode and n in (getattr(self, "_graphs", None) or {}):
             # the batch's device work — reset, fills, the three launches — was captured (enable_graph): two small uploads
             # and ONE graph launch instead of ~10 eager launches (~200 us of host time, which a short run cannot hide)
             return self.rollout_graphed(n)
-        self._upload_eps_schedule(eps)
+        self._upload_eps_schedule(self._eps_schedule(n, test_mode))
         self.begin_episodes()                       # episode index, zero hidden state, env reset, static rows + inputs
         self._ctr_base.fill_(self._ep * (T + 1))
         self._fused_launches(n, test_mode=test_mode)
