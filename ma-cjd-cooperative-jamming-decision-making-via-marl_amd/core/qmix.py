@@ -791,6 +791,11 @@ class QMixLearner:
                          and options.on("PIPELINED_GROUP"))
             stage2 = {k: torch.zeros_like(v) for k, v in stage.items()} if pipelined else None
             stages = [stage, stage2]
+            # (the captured launches write and read the second staging set through baked addresses: it has to live as long
+            # as the graph.  Until round 3 nothing held it once this function returned — the freed blocks stayed cached, so
+            # it went unnoticed until another capture's torch.cuda.empty_cache() unmapped them: a GPU memory fault in the
+            # first replay of the group at 12j/16r.)
+            self._g_stages = stages
             origin_dev = self.device
 
             def prefetch(dst, fork=True, draw=True):
@@ -888,7 +893,7 @@ class QMixLearner:
             graphs.append(m[1])
         graphs += [getattr(self, "_graph_b", None), getattr(self, "_graph_a", None)]
         self._graphs_ready = False
-        self._g_multi = None
+        self._g_multi = self._g_stages = None
         self._graph_a = self._graph_b = None
         self._graph_body_a = None
         self._g_out_a = self._g_out_b = self._g_stats4 = self._last_stats4 = self._held_ln = None

@@ -26,8 +26,9 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 J, R = int(os.environ.get("JAMMERS", 3)), int(os.environ.get("RADARS", 4))
 dev = torch.device("cuda", 0)
 sc = Scenario.from_dict(ring_scenario_dict(J, R))
-env = BatchedElectromagneticEnvironment(scenario=sc, batch_envs=4096, device=dev, seed=1)
-args = bench_rollout.make_args(sc, 64, dev, batch_envs=4096)
+E = int(os.environ.get("BATCH_ENVS", 4096))
+env = BatchedElectromagneticEnvironment(scenario=sc, batch_envs=E, device=dev, seed=1)
+args = bench_rollout.make_args(sc, 64, dev, batch_envs=E, mixer_dtype=os.environ.get("MIXER_DTYPE", "fp32"))
 torch.manual_seed(42)
 with contextlib.redirect_stdout(io.StringIO()):
     mac = BasicMAC(args.obs_shape, args)

@@ -1827,6 +1827,12 @@ def test_updates_grouped_into_one_graph_equal_single_updates(paired, monkeypatch
         buf.current_size, buf.current_index = N, 0
         buf.episode_lengths[:] = T
         learner.enable_graphs(buf, B, updates_per_graph=k)
+        # every address baked into the captured launches must belong to a tensor that is still alive: cached blocks of
+        # freed tensors go back to the driver here, as they do at the start of any later capture (round 3: the group's
+        # second staging set was such a tensor — a GPU memory fault at 12j/16r once the rollout was captured afterwards)
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
         return mac, learner
     mac_1, one = build(1)
     mac_k, many = build(K)
