@@ -14,6 +14,9 @@ run() {  # name, bench args...
   rm -rf $OUT/prof_$name
   echo "[configs] $name profile done"
 }
-run c3_6j8r --jammers 6 --radars 8
-run c5_12j16r_fp32 --jammers 12 --radars 16 --batch-envs 2048
-run c5_12j16r_bf16 --jammers 12 --radars 16 --batch-envs 2048 --mixer-dtype bf16
+# ONLY="c5" scripts/collect_configs.sh <tag>: just the configurations whose name contains $ONLY
+want() { [ -z "$ONLY" ] || [[ "$1" == *"$ONLY"* ]]; }
+want c3_6j8r && run c3_6j8r --jammers 6 --radars 8
+want c5_12j16r_fp32 && run c5_12j16r_fp32 --jammers 12 --radars 16 --batch-envs 2048
+want c5_12j16r_bf16 && run c5_12j16r_bf16 --jammers 12 --radars 16 --batch-envs 2048 --mixer-dtype bf16
+true
