@@ -535,12 +535,9 @@ class QMixLearner:
 
     def _paired_heads_ok(self, st, T):
         """A prefetched update can take its target branch as paired launches on the chain's stream (ops.pair_*): HIP device,
-        two streams, the one-launch forms of both Q-heads and both mixers apply, MACJD_PAIRED_HEADS not 0 — and at most 6
-        agents: at 12 the mixer grid is the pass-based kernel at one workgroup per CU, so the pair runs as two rounds
-        behind each other and the target branch is better off on the side stream (12j/16r: 388 vs 375 us / update;
-        6j/8r: 179 vs 185; 3j/4r: 111 vs 117 with the same weight-gradient kernels)."""
-        if self.n_agents > 6 and options.get("PAIRED_HEADS") != "force":
-            return False
+        two streams, the one-launch forms of both Q-heads and both mixers apply, MACJD_PAIRED_HEADS not 0.  (us / update,
+        paired vs side-stream target branch: 3j/4r 111 vs 117, 6j/8r 179 vs 185, 12j/16r 318 vs 328 — at 12 agents only
+        since the 33-action Double-DQN body stopped spilling: before, the pair was the slower form there, 388 vs 375.)"""
         B, T1 = st["state"].shape[0], T + 1
         J, H, A = self.n_agents, self.args.rnn_hidden_dim, self.n_actions
         n = B * T1 * J

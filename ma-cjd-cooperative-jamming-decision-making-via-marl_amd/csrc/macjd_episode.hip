@@ -376,7 +376,10 @@ __device__ __forceinline__ void qhead_double_q_body(const macjd_doubleq_io& io, 
 #pragma unroll
         for (int a = 0; a < AH; ++a) q[a] = 0.0f;
         const float* brow = &Bs[head][qr * EP_LD + 16 * qq];
-#pragma unroll
+        // (33 actions: fully unrolled, the compiler hoists all 16 x 19 LDS reads of the lane's units in front of the
+        // arithmetic — 256 VGPRs + spills, one workgroup per CU, 118 us for 38 784 rows; unit groups of four one after
+        // the other keep ~80 values live)
+#pragma unroll(A > 17 ? 1 : 4)
         for (int k4 = 0; k4 < 4; ++k4) {
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + 4 * k4);
 #pragma unroll

@@ -15,8 +15,7 @@ for normal operation.
     MACJD_WGRAD_OUTER         1 | 0      Q-head ReLU-backward operand formed inside the weight-gradient launch
     MACJD_QHEAD_TAKEN         1 | 0      taken-action Q-head as one launch / input rows + GEMM + row-dot
     MACJD_PAIRED_HEADS        1 | 0      pipelined update: both Q-head launches as one grid and both mixers as one grid on
-                                         the chain's stream (up to 6 agents; "force": any) / target branch on the side
-                                         stream beside the eval head
+                                         the chain's stream / target branch on the side stream beside the eval head
     MACJD_GRAPHED_ALLREDUCE   0 | 1      with ranks: RCCL all-reduce captured inside the update graph
 """
 from __future__ import annotations
