@@ -181,3 +181,26 @@ def test_graph_launch_queue_reservation_rules():
     assert run(GPU_MAX_HW_QUEUES="4") == ["4", "current"]
     assert run(GPU_MAX_HW_QUEUES="4", MACJD_GRAPH_REPLAY_STREAM="high") == ["4", "high"]
     assert run(MACJD_GRAPH_REPLAY_STREAM="current") == ["3", "current"]
+
+
+def test_batch_exploration_schedule_equals_the_selectors_anneal():
+    """The runner computes the exploration probabilities of a whole episode batch in one vector expression
+    (BatchedEpisodeRunner._eps_schedule): bit-equal (as float32) to calling the selector's anneal() step by step
+    (reference utils/action_selectors.py:30-32), the selector left at the same epsilon, test mode frozen."""
+    import numpy as np
+    from macjd_amd.runners.episode_runner import BatchedEpisodeRunner
+    from macjd_amd.utils.action_selectors import EpsilonGreedyActionSelector
+
+    def selector():
+        return EpsilonGreedyActionSelector(SimpleNamespace(epsilon_start=1.0, epsilon_finish=0.05, epsilon_anneal_time=777))
+
+    for t_env, n in ((0, 100), (700, 100), (123, 20), (5000, 7)):
+        a, b = selector(), selector()
+        want = np.zeros(100, dtype=np.float32)
+        for t in range(n):
+            want[t] = a.anneal(t_env + t)
+        stub = SimpleNamespace(mac=SimpleNamespace(action_selector=b), t_env=t_env, episode_limit=100)
+        got = BatchedEpisodeRunner._eps_schedule(stub, n, False)
+        assert got.dtype == np.float32 and np.array_equal(got, want) and b.epsilon == a.epsilon
+        frozen = BatchedEpisodeRunner._eps_schedule(stub, n, True)
+        assert np.array_equal(frozen[:n], np.full(n, np.float32(b.epsilon))) and not frozen[n:].any() and b.epsilon == a.epsilon
