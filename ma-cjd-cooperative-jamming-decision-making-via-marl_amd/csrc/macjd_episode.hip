@@ -341,12 +341,14 @@ __device__ __forceinline__ void qhead_double_q_body(const macjd_doubleq_io& io, 
         const float* src = (which ? io.h_t + nn * io.ht_ld : io.h_e + nn * io.he_ld) + 4 * c4;
         *reinterpret_cast<f32x4*>(&Hs[which][row * EP_LD + 4 * c4]) = *reinterpret_cast<const f32x4_u*>(src);
     }
+    // (consecutive lanes walk along a ROW of W1 — its A + 1 action / power columns are contiguous — rather than down a
+    // column: a column walk is one cache line per element, 2 x 64 x (A + 1) line requests per workgroup)
     for (int idx = threadIdx.x; idx < 2 * (A + 2) * EP_H; idx += 256) {
         const int which = idx / ((A + 2) * EP_H), rem = idx - which * (A + 2) * EP_H;
-        const int a = rem / EP_H, uu = rem - a * EP_H;
+        const int uu = rem / (A + 2), a = rem - uu * (A + 2);
         const float* W1 = which ? io.W1_t : io.W1_e;
         const int64_t ld = which ? io.w1t_ld : io.w1e_ld;
-        Wq[which][rem] = (a <= A) ? W1[(int64_t)uu * ld + EP_H + a] : (which ? io.w2_t : io.w2_e)[uu];
+        Wq[which][a * EP_H + uu] = (a <= A) ? W1[(int64_t)uu * ld + EP_H + a] : (which ? io.w2_t : io.w2_e)[uu];
     }
     __syncthreads();
     {
@@ -467,9 +469,9 @@ __device__ __forceinline__ void qhead_taken_body(const macjd_qtaken_io& io, cons
         *reinterpret_cast<f32x4*>(&Hl[row >> 4][(row & 15) * EP_LD + 4 * c4]) =
             *reinterpret_cast<const f32x4*>(io.h + rc * io.h_ld + 4 * c4);
     }
-    for (int i = threadIdx.x; i < (A + 1) * EP_H; i += 256) {
-        const int a = i / EP_H, uu = i - a * EP_H;
-        Wc[i] = io.W1[(int64_t)uu * io.w1_ld + EP_H + a];
+    for (int i = threadIdx.x; i < (A + 1) * EP_H; i += 256) {   // (along W1's rows, as in the Double-DQN body)
+        const int uu = i / (A + 1), a = i - uu * (A + 1);
+        Wc[a * EP_H + uu] = io.W1[(int64_t)uu * io.w1_ld + EP_H + a];
     }
     if (threadIdx.x < QT_TILES * 16) {
         const int64_t rc = (r0 + threadIdx.x < io.n_rows) ? r0 + threadIdx.x : io.n_rows - 1;
