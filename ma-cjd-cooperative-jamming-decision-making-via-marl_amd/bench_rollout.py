@@ -129,16 +129,21 @@ def make_step(cli, sc, env, dev, rank, world, mode):
     step_fn = _make_step_fn(cli, runner, learner if mode == "train" else None, buf, args, T, mode, use_graphs, tails)
     step_fn.runner, step_fn.learner, step_fn.buffer = runner, learner, buf   # (for tests and probes)
 
+    st0 = (getattr(learner, "_g_stages", None) or [None])[0]   # the grouped update's first staging set (None: no group captured)
     extra = {"hidden": cli.hidden, "train_batch_episodes": args.batch_size if mode == "train" else 0,
              "train_calls_per_step": 1 if mode == "train" else 0,
              "updates_per_graph": (learner._g_multi[0] if (mode == "train" and use_graphs and learner._g_multi) else 1),
              "hip_graphs": bool(use_graphs), "gemm_tuning": bool(gemm_tuning),
              "graph_launch": {"stream": hipgraph.launch_mode(), "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                               "allreduce_in_graph": bool(getattr(learner, "_g_graphed_ar", False))},
+             "update": (("paired: Q-head launches as one grid, mixers as one grid, the chain on one queue"
+                         if learner._paired_heads_ok(st0, learner._g_T) else "target branch on the side stream")
+                        if (mode == "train" and use_graphs and st0 is not None) else None),
              "replay_capacity_episodes": args.buffer_size, "mixer_dtype": args.mixer_dtype,
              "mixer": ("one MFMA launch per direction (f32)" if (mode == "train" and learner.eval_qmix_net.fused_available(next(learner.eval_qmix_net.parameters())))
                        else ("library GEMMs (%s) + tail kernel" % args.mixer_dtype)) if mode == "train" else None,
-             "rollout": "fused: agent-episode launch + many-step env launch per episode batch" if fused_rollout else
+             "rollout": ("fused: agent-episode launch + many-step env launch per episode batch" +
+                         (", replayed as one graph" if use_graphs else "")) if fused_rollout else
                         ("HIP graph of the step-by-step rollout" if use_graphs else "eager step-by-step")}
     return step_fn, extra
 
