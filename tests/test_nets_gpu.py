@@ -1400,7 +1400,8 @@ def test_fused_gather_rows():
     assert not ops.gather_rows_supported([torch.zeros(4, 5, dtype=torch.bool, device=DEV)])   # 5-byte rows
 
 
-@pytest.mark.parametrize("K,M,N", [(3232, 384, 46), (9696, 64, 74), (3232, 1, 64), (1030, 192, 128), (3232, 64, 128)])
+@pytest.mark.parametrize("K,M,N", [(3232, 384, 46), (9696, 64, 74), (3232, 1, 64), (1030, 192, 128), (3232, 64, 128),
+                                   (9696, 1, 64), (1031, 1, 46), (777, 1, 100)])   # (one-row outputs: the row-vector work items)
 def test_split_k_weight_gradient_kernel(K, M, N):
     """Split-K MFMA weight / bias gradient vs a float64 reference, incl. row-strided operands and the autograd
     Function it sits in (forward / input gradient stay library GEMMs)."""
