@@ -381,7 +381,8 @@ __device__ __forceinline__ void qhead_double_q_body(const macjd_doubleq_io& io, 
         // (33 actions: fully unrolled, the compiler hoists all 16 x 19 LDS reads of the lane's units in front of the
         // arithmetic — 256 VGPRs + spills, one workgroup per CU, 118 us for 38 784 rows; unit groups of four one after
         // the other keep ~80 values live)
-#pragma unroll(A > 17 ? 1 : 4)
+        constexpr int K4_UNROLL = A > 17 ? 1 : 4;
+#pragma unroll K4_UNROLL
         for (int k4 = 0; k4 < 4; ++k4) {
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + 4 * k4);
 #pragma unroll
