@@ -297,6 +297,11 @@ class BatchedEpisodeRunner:
         with hipgraph.capture(graph):
             self._rollout_body(device_schedule=True, n_steps=n)
         self._graphs[n] = graph
+        # the tensors the captured launches were handed through attributes that later (eager) rollouts replace: held for
+        # the graph's lifetime, and the MAC's recurrent state is pointed back at the captured one after each replay
+        if getattr(self, "_graph_keep", None) is None:
+            self._graph_keep = {}
+        self._graph_keep[n] = (self.mac.hidden_states, getattr(self.mac, "static_inputs", None), self._avail, self._obs)
         if n == T:
             self._graph = graph
         if env_ep0 is not None:
@@ -309,7 +314,7 @@ class BatchedEpisodeRunner:
         to the fused / step-by-step rollout until ``enable_graph`` is called again."""
         from .. import hipgraph
         graphs = list((getattr(self, "_graphs", None) or {}).values())
-        self._graphs, self._graph = None, None
+        self._graphs, self._graph, self._graph_keep = None, None, None
         hipgraph.destroy(list(reversed(graphs)), self.device)
 
     def _rollout_body(self, device_schedule=False, n_steps=None):
@@ -333,6 +338,7 @@ class BatchedEpisodeRunner:
         self._ctr_base.fill_(self._ep * (T + 1))
         from .. import hipgraph
         hipgraph.replay(self._graphs[n], self.device)
+        self.mac.hidden_states = self._graph_keep[n][0]   # h after the batch's last step, as the eager rollout leaves it
         self.t_env += n
 
     # ---- whole-episode launches: the agent's T steps as one kernel, the env's T steps as another ----

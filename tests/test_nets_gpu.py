@@ -837,6 +837,8 @@ def test_graphed_rollout_equals_eager_rollout(fused):
         np.testing.assert_allclose(ie["action_distribution"], ig["action_distribution"], atol=1e-7)
     assert r_e.t_env == r_g.t_env == 200
     assert m_e.action_selector.epsilon == pytest.approx(m_g.action_selector.epsilon)
+    # the MAC's recurrent state after the batch is the captured launches' final h, not a stale eager tensor
+    np.testing.assert_allclose(m_g.hidden_states.cpu().numpy(), m_e.hidden_states.cpu().numpy(), atol=1e-6, rtol=0)
     for k in b_e.buffers:
         a, b = b_e.buffers[k], b_g.buffers[k]
         if a.dtype.is_floating_point:
